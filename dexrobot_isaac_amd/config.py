@@ -224,7 +224,8 @@ def build_sim_config(cfg, model=None, dr=None):
     c.rest_offset = float(px["rest_offset"])
     c.max_depenetration_velocity = float(px["max_depenetration_velocity"])
     c.erp = float(sim.get("dexsim_erp", 0.2))
-    c.control_dt = 2.0 * c.dt
+    control_dt = 2.0 * float(sim["dt"])   # python double, as PhysicsManager computes it (physics_manager.py:259)
+    c.control_dt = control_dt
     c.episode_length = int(env["episodeLength"])
     c.seed = int(cfg["train"]["seed"]) & 0xFFFFFFFF
 
@@ -240,7 +241,7 @@ def build_sim_config(cfg, model=None, dr=None):
     for i in range(18):
         lim = (task["max_base_linear_velocity"] if i < 3 else
                task["max_base_angular_velocity"] if i < 6 else task["max_finger_joint_velocity"])
-        c.max_deltas[i] = c.control_dt * float(lim)
+        c.max_deltas[i] = control_dt * float(lim)
     lo, hi = active_limits(model)
     for i in range(18):
         c.active_lower[i], c.active_upper[i] = lo[i], hi[i]
@@ -305,7 +306,7 @@ def build_sim_config(cfg, model=None, dr=None):
         c.box_z = float(box["initial_position"]["z"])
         c.height_threshold = float(task["success_height_threshold"])
         c.contact_duration_threshold_s = float(task["contact_duration_threshold"])
-        c.contact_duration_threshold_steps = int(c.contact_duration_threshold_s / c.control_dt)
+        c.contact_duration_threshold_steps = int(float(task["contact_duration_threshold"]) / control_dt)
         c.min_fingers_for_grasp = int(task["min_fingers_for_grasp"])
         c.max_box_distance = float(task["max_box_distance"])
         c.stage1_duration, c.stage2_duration = float(task["stage1_duration"]), float(task["stage2_duration"])

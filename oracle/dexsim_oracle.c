@@ -149,6 +149,10 @@ typedef struct OrcEnv {
   real site_pose[DEXSIM_NSITE][7];
   real hand_vel[6];
   real cforce[DEXSIM_NFSLOT][3];
+  /* TensorManager.contact_forces: the (N,5,3) gather COPY made by refresh_tensors at the start of
+   * process_physics_step (tensor_manager.py:441-446, step_processor.py:46-48).  The first observation pass
+   * of DexHandBase.reset() runs before that refresh and therefore sees the previous copy. */
+  real cf5[5][3];
   int ncontact;
   OrcContact contact[KMAX];
   /* L2 state */
@@ -696,7 +700,10 @@ enum { O_base_dof_pos = 0, O_base_dof_vel = 6, O_active_finger_dof_pos = 12, O_a
        O_thumb_contact = 385, O_other_fingers_contact = 386, O_grasp_state = 387, O_grasp_duration = 388,
        O_current_stage = 389, O_time_in_stage = 390, O_stage_progress = 391 };
 
-static inline const real* finger_cforce(const OrcEnv* e, int f) { return e->cforce[3 * f + 2]; } /* r_f_link{f+1}_4 */
+static inline const real* finger_cforce(const OrcEnv* e, int f) { return e->cf5[f]; }
+static inline void refresh_cf5(OrcEnv* e) { /* r_f_link{f+1}_4 = force slot 3f+2 */
+  for (int f = 0; f < 5; f++) for (int i = 0; i < 3; i++) e->cf5[f][i] = e->cforce[3 * f + 2][i];
+}
 
 /* blind_grasping_task.py:773-833 */
 static void detect_finger_box_contacts(const Oracle* o, const OrcEnv* e, const real* ob, int* out) {
@@ -1115,6 +1122,7 @@ void orc_post_physics(void* h, int obs_only) {
   PAR_FOR
   for (int i = 0; i < o->n; i++) {
     OrcEnv* e = &o->env[i];
+    if (!obs_only) refresh_cf5(e);
     compute_observations_env(o, e);
     concat_observations_env(o, e, i);
     if (obs_only) continue;
@@ -1171,6 +1179,7 @@ static const FieldDesc FIELDS[] = {
   {"box_pos", 3, 0, OFF(box_pos)}, {"box_quat", 4, 0, OFF(box_quat)}, {"box_lin", 3, 0, OFF(box_lin)},
   {"box_ang", 3, 0, OFF(box_ang)}, {"box_mass", 1, 0, OFF(box_mass)}, {"box_mu", 1, 0, OFF(box_mu)},
   {"site_pose", 77, 0, OFF(site_pose)}, {"hand_vel", 6, 0, OFF(hand_vel)}, {"cforce", 51, 0, OFF(cforce)},
+  {"cf5", 15, 0, OFF(cf5)},
   {"ncontact", 1, 1, OFF(ncontact)},
   {"active_prev_targets", 18, 0, OFF(active_prev_targets)}, {"active_rule_targets", 18, 0, OFF(active_rule_targets)},
   {"prev_actions", 18, 0, OFF(prev_actions)}, {"actions", 18, 0, OFF(actions)}, {"prev_dof_pos", NJ, 0, OFF(prev_dof_pos)},
@@ -1248,6 +1257,7 @@ void orc_l2_step_no_reset(void* h) { /* obs + count + termination + reward, WITH
   int first = o->rc_first_call;
   for (int i = 0; i < o->n; i++) {
     OrcEnv* e = &o->env[i];
+    refresh_cf5(e);
     compute_observations_env(o, e);
     concat_observations_env(o, e, i);
     e->episode_step += 1;
