@@ -1,0 +1,37 @@
+"""Build libdexsim.so (HIP, gfx950 only) in-tree with hipcc.  No JIT cache: the .so sits next to the package
+so that it travels with the repo snapshot and shows up as loaded native code."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdexsim.so")
+SOURCES = ["dexsim.hip", "dexsim_device.h", "dexsim_physics.hip.inc", "dexsim_l2.hip.inc"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "dexsim.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the path of the library."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libdexsim.so cannot be built on this machine")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
+           "-o", LIB, os.path.join(CSRC, "dexsim.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

@@ -1,0 +1,395 @@
+// dexsim.hip -- libdexsim: C-ABI (include/dexsim.h) over the gfx950 kernels.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared -o libdexsim.so dexsim.hip
+// No torch types, no CUDA shims, no dual back-end: this file only targets CDNA4 through HIP.
+#include "dexsim_device.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+// clang-format off
+#include "dexsim_physics.hip.inc"
+#include "dexsim_l2.hip.inc"
+// clang-format on
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* what) {
+  g_last_error = what ? what : "";
+  return code;
+}
+#define HIP_TRY(expr)                                                                 \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      return DEXSIM_ERR_HIP;                                                          \
+    }                                                                                 \
+  } while (0)
+
+struct DexSim {
+  DexSimConfig cfg;
+  DexHandModel model;
+  int device;
+  int N;  // real envs
+  int NS; // padded to a multiple of 64: arena stride, every lane of every wavefront owns an env
+  DevParams* d_params;
+  Arena arena;
+  ApiPtrs api;
+  bool bound;
+  hipEvent_t ev0, ev1;
+};
+
+static int padded(int n) { return (n + 63) / 64 * 64; }
+
+static const char* const kObsKeyNames[] = {
+#define X(name, dim) #name,
+    DEXSIM_OBS_KEYS(X)
+#undef X
+};
+static const int kObsKeyDims[] = {
+#define X(name, dim) dim,
+    DEXSIM_OBS_KEYS(X)
+#undef X
+};
+static const char* const kRewardNames[] = {
+#define X(name) #name,
+    DEXSIM_REWARD_TERMS(X)
+#undef X
+};
+
+extern "C" {
+
+int dexsim_struct_sizes(size_t out[4]) {
+  out[0] = sizeof(DexHandModel); out[1] = sizeof(DexSimConfig); out[2] = sizeof(DexSimField); out[3] = sizeof(DexSimBuffers);
+  return DEXSIM_OK;
+}
+
+int dexsim_arena_layout(const DexSimConfig* cfg, DexSimField* fields, int max_fields, int* n_fields, size_t* arena_words) {
+  if (!cfg || !n_fields || !arena_words || cfg->num_envs <= 0) return fail(DEXSIM_ERR_ARG, "dexsim_arena_layout: bad argument");
+  const size_t NS = (size_t)padded(cfg->num_envs);
+  size_t off = 0;
+  int n = 0;
+#define X(ty, nm, nrows)                                                      \
+  {                                                                           \
+    if (fields) {                                                             \
+      if (n >= max_fields) return fail(DEXSIM_ERR_LAYOUT, "field table too small"); \
+      std::snprintf(fields[n].name, sizeof fields[n].name, "%s", #nm);        \
+      fields[n].rows = (nrows);                                               \
+      fields[n].is_int = std::string(#ty) == "int"; \
+      fields[n].offset = off;                                                 \
+    }                                                                         \
+    off += (size_t)(nrows) * NS;                                              \
+    n++;                                                                      \
+  }
+  DEXSIM_FIELDS(X)
+#undef X
+  *n_fields = n;
+  *arena_words = off;
+  return DEXSIM_OK;
+}
+
+int dexsim_obs_key_info(int i, const char** name, int* offset, int* dim) {
+  if (i < 0 || i >= DEXSIM_NUM_OBS_KEYS) return fail(DEXSIM_ERR_ARG, "obs key index out of range");
+  int off = 0;
+  for (int k = 0; k < i; k++) off += kObsKeyDims[k];
+  if (name) *name = kObsKeyNames[i];
+  if (offset) *offset = off;
+  if (dim) *dim = kObsKeyDims[i];
+  return DEXSIM_OK;
+}
+
+int dexsim_reward_term_name(int i, const char** name) {
+  if (i < 0 || i >= DEXSIM_NUM_REWARD_TERMS || !name) return fail(DEXSIM_ERR_ARG, "reward term index out of range");
+  *name = kRewardNames[i];
+  return DEXSIM_OK;
+}
+
+int dexsim_body_name(int i, const char** name) {
+  static char names[DEXSIM_NUM_HAND_BODIES][24];
+  static bool init = false;
+  if (!init) {
+    const char* base[7] = {"hand_mount", "ARTx_link", "ARTy_link", "ARTz_link", "ARRx_link", "ARRy_link", "right_hand_base"};
+    for (int b = 0; b < 7; b++) std::snprintf(names[b], 24, "%s", base[b]);
+    const char* suf[6] = {"1", "2", "3", "4", "pad", "tip"};
+    for (int f = 0; f < 5; f++)
+      for (int l = 0; l < 6; l++) std::snprintf(names[7 + 6 * f + l], 24, "r_f_link%d_%s", f + 1, suf[l]);
+    init = true;
+  }
+  if (i < 0 || i >= DEXSIM_NUM_HAND_BODIES || !name) return fail(DEXSIM_ERR_ARG, "body index out of range");
+  *name = names[i];
+  return DEXSIM_OK;
+}
+
+static int validate_model(const DexHandModel& m) {
+  for (int j = 0; j < DEXSIM_NJ; j++)
+    if (m.jtype[j] != (j < 3 ? 0 : 1)) return fail(DEXSIM_ERR_ARG, "model: kernels assume joints 0-2 prismatic, 3-25 revolute");
+  for (int j = 0; j < 5; j++)
+    if (m.mass[j] != 0.f) return fail(DEXSIM_ERR_ARG, "model: base-chain links 0-4 must be massless (palm rides on joint 5)");
+  for (int j = 5; j < DEXSIM_NJ; j++)
+    if (!(m.mass[j] > 0.f)) return fail(DEXSIM_ERR_ARG, "model: palm and finger links need positive mass");
+  for (int c = 0; c < DEXSIM_NCAP; c++) {
+    const int want = c < 3 ? 5 : 6 + 4 * ((c - 3) / 3) + 1 + (c - 3) % 3;
+    if (m.cap_parent[c] != want) return fail(DEXSIM_ERR_ARG, "model: capsule c must ride on palm (c<3) or finger link (c-3)/3,(c-3)%3+1");
+    if (m.cap_fslot[c] < 0 || m.cap_fslot[c] >= DEXSIM_FSLOT_BOX) return fail(DEXSIM_ERR_ARG, "model: bad capsule force slot");
+  }
+  if (m.site_parent[0] != 5) return fail(DEXSIM_ERR_ARG, "model: site 0 (right_hand_base) must ride on joint 5");
+  for (int f = 0; f < 5; f++)
+    if (m.site_parent[1 + f] != 9 + 4 * f || m.site_parent[6 + f] != 9 + 4 * f)
+      return fail(DEXSIM_ERR_ARG, "model: tip/pad sites must ride on the distal joint of their finger");
+  for (int j = 0; j < DEXSIM_NJ; j++)
+    if (!(m.hi[j] > m.lo[j])) return fail(DEXSIM_ERR_ARG, "model: joint range must be non-empty");
+  return DEXSIM_OK;
+}
+
+int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device, dexsim_t* out) {
+  if (!cfg || !model || !out) return fail(DEXSIM_ERR_ARG, "dexsim_create: null argument");
+  if (cfg->num_envs <= 0 || cfg->substeps <= 0 || !(cfg->dt > 0.f)) return fail(DEXSIM_ERR_ARG, "dexsim_create: bad num_envs/substeps/dt");
+  if (cfg->num_obs <= 0 || cfg->n_obs_seg <= 0 || cfg->n_obs_seg > DEXSIM_MAX_OBS_SEG) return fail(DEXSIM_ERR_ARG, "dexsim_create: bad observation table");
+  if (cfg->num_actions != 6 * (cfg->policy_controls_base != 0) + 12 * (cfg->policy_controls_fingers != 0) || cfg->num_actions == 0)
+    return fail(DEXSIM_ERR_ARG, "dexsim_create: num_actions inconsistent with policy_controls_*");
+  if (cfg->has_box && !(cfg->box_size > 0.f && cfg->box_mass > 0.f)) return fail(DEXSIM_ERR_ARG, "dexsim_create: bad box");
+  {
+    int tot = 0;
+    for (int s = 0; s < cfg->n_obs_seg; s++) {
+      if (cfg->obs_seg_off[s] < 0 || cfg->obs_seg_len[s] <= 0 || cfg->obs_seg_off[s] + cfg->obs_seg_len[s] > DEXSIM_OBS_ALL_DIM)
+        return fail(DEXSIM_ERR_ARG, "dexsim_create: observation segment out of range");
+      tot += cfg->obs_seg_len[s];
+    }
+    if (tot != cfg->num_obs) return fail(DEXSIM_ERR_ARG, "dexsim_create: num_obs != sum of segments");
+  }
+  int rc = validate_model(*model);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DEXSIM_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(DEXSIM_ERR_NO_DEVICE, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  DexSim* h = new DexSim();
+  h->cfg = *cfg; h->model = *model; h->device = device;
+  h->N = cfg->num_envs; h->NS = padded(cfg->num_envs);
+  h->bound = false;
+  DevParams hp;
+  hp.cfg = *cfg; hp.model = *model;
+  hp.h = cfg->dt / (float)cfg->substeps;
+  hp.box_inv_I_k = cfg->has_box ? 6.f / (cfg->box_size * cfg->box_size) : 0.f;
+  HIP_TRY(hipMalloc(&h->d_params, sizeof(DevParams)));
+  HIP_TRY(hipMemcpy(h->d_params, &hp, sizeof(DevParams), hipMemcpyHostToDevice));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  *out = h;
+  return DEXSIM_OK;
+}
+
+int dexsim_destroy(dexsim_t h) {
+  if (!h) return DEXSIM_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipFree(h->d_params);
+  (void)hipEventDestroy(h->ev0);
+  (void)hipEventDestroy(h->ev1);
+  delete h;
+  return DEXSIM_OK;
+}
+
+int dexsim_bind(dexsim_t h, const DexSimBuffers* b) {
+  if (!h || !b) return fail(DEXSIM_ERR_ARG, "dexsim_bind: null argument");
+  if (!b->arena || !b->stats || !b->counters || !b->obs_buf || !b->rew_buf || !b->reset_buf || !b->episode_step_count ||
+      !b->episode_length || !b->dof_state || !b->root_state)
+    return fail(DEXSIM_ERR_ARG, "dexsim_bind: arena, stats, counters, obs_buf, rew_buf, reset_buf, episode_step_count, "
+                                "episode_length, dof_state and root_state are required");
+  size_t off = 0;
+  const size_t NS = (size_t)h->NS;
+  char* base = (char*)b->arena;
+#define X(ty, nm, nrows)                           \
+  h->arena.nm = (ty*)(base + off * 4);           \
+  off += (size_t)(nrows) * NS;
+  DEXSIM_FIELDS(X)
+#undef X
+  h->api.obs_buf = b->obs_buf; h->api.rew_buf = b->rew_buf; h->api.reset_buf = b->reset_buf;
+  h->api.episode_step_count = b->episode_step_count; h->api.episode_length = b->episode_length;
+  h->api.dof_state = b->dof_state; h->api.root_state = b->root_state;
+  h->api.rigid_body_states = b->rigid_body_states; h->api.contact_forces_all = b->contact_forces_all;
+  h->api.full_dof_targets = b->full_dof_targets; h->api.reset_samples = b->reset_samples;
+  h->api.stats = b->stats; h->api.counters = b->counters;
+  h->bound = true;
+  return DEXSIM_OK;
+}
+
+#define NEED_BOUND(h)                                                        \
+  if (!(h)) return fail(DEXSIM_ERR_ARG, "null handle");                      \
+  if (!(h)->bound) return fail(DEXSIM_ERR_NOT_BOUND, "dexsim_bind has not been called")
+#define GRID(h) dim3((h)->NS / 64), dim3(64), 0, (hipStream_t)stream
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+static int launch_publish(dexsim_t h, int gate, int full, void* stream) {
+  k_publish<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, gate, full, h->NS, h->N);
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
+
+int dexsim_init_state(dexsim_t h, void* stream) {
+  NEED_BOUND(h);
+  size_t words = 0; int nf = 0;
+  dexsim_arena_layout(&h->cfg, nullptr, 0, &nf, &words);
+  HIP_TRY(hipMemsetAsync(h->arena.q, 0, words * 4, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(h->api.episode_step_count, 0, sizeof(int64_t) * h->N, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(h->api.episode_length, 0, sizeof(int64_t) * h->N, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(h->api.reset_buf, 0, h->N, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(h->api.rew_buf, 0, sizeof(float) * h->N, (hipStream_t)stream));
+  k_init<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->NS, h->N);
+  LAUNCH_CHECK();
+  return launch_publish(h, 0, 0, stream);
+}
+
+int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, void* stream) {
+  NEED_BOUND(h);
+  if (!actions) return fail(DEXSIM_ERR_ARG, "Actions cannot be None");   // action_processor.py:296-297
+  k_actions<<<GRID(h)>>>(h->arena, h->api, h->d_params, actions, zero_targets, h->NS, h->N);
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
+
+int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
+  NEED_BOUND(h);
+  for (int s = 0; s < h->cfg.substeps; s++) {
+    k_dynamics<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, gate_on_reset, h->NS);
+    LAUNCH_CHECK();
+    k_solve<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, gate_on_reset, s == h->cfg.substeps - 1, h->NS);
+    LAUNCH_CHECK();
+  }
+  return launch_publish(h, gate_on_reset, 0, stream);
+}
+
+int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
+  NEED_BOUND(h);
+  k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, h->NS, h->N);
+  LAUNCH_CHECK();
+  if (obs_only) return DEXSIM_OK;
+  // reset_idx(nonzero(reset_buf)) incl. the extra physics step for ALL envs (step_processor.py:109-111,
+  // reset_manager.py:180), gated on the device-side flag instead of torch.any() on the host
+  k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 0, h->NS, h->N);
+  LAUNCH_CHECK();
+  int rc = dexsim_physics_step(h, 1, stream);
+  if (rc) return rc;
+  k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 1, h->NS, h->N);
+  LAUNCH_CHECK();
+  k_finalize<<<1, 64, 0, (hipStream_t)stream>>>(h->api, h->d_params, h->N);
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
+
+int dexsim_step(dexsim_t h, const float* actions, void* stream) {
+  NEED_BOUND(h);
+  k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters);
+  LAUNCH_CHECK();
+  int rc = dexsim_process_actions(h, actions, 0, stream);
+  if (rc) return rc;
+  rc = dexsim_physics_step(h, 0, stream);
+  if (rc) return rc;
+  return dexsim_post_physics(h, 0, stream);
+}
+
+int dexsim_reset_idx(dexsim_t h, const int64_t* env_ids, int k, void* stream) {
+  NEED_BOUND(h);
+  if (k == 0) return DEXSIM_OK;   // dexhand_base.py:746-747
+  if (k < 0 || (!env_ids && k != h->N)) return fail(DEXSIM_ERR_ARG, "dexsim_reset_idx: bad env_ids");
+  const int mode = env_ids ? 1 : 2;
+  dim3 grid((k + 63) / 64);
+  k_reset<<<grid, 64, 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, env_ids, k, mode, 0, h->NS, h->N);
+  LAUNCH_CHECK();
+  int rc = dexsim_physics_step(h, 0, stream);
+  if (rc) return rc;
+  k_reset<<<grid, 64, 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, env_ids, k, mode, 1, h->NS, h->N);
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
+
+int dexsim_reset(dexsim_t h, void* stream) {
+  NEED_BOUND(h);
+  k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters);
+  LAUNCH_CHECK();
+  int rc = dexsim_reset_idx(h, nullptr, h->N, stream);
+  if (rc) return rc;
+  rc = dexsim_post_physics(h, 1, stream);
+  if (rc) return rc;
+  return dexsim_post_physics(h, 0, stream);
+}
+
+int dexsim_refresh_body_states(dexsim_t h, void* stream) {
+  NEED_BOUND(h);
+  if (!h->api.rigid_body_states || !h->api.contact_forces_all) return fail(DEXSIM_ERR_NOT_BOUND, "rigid_body_states / contact_forces_all not bound");
+  return launch_publish(h, 0, 1, stream);
+}
+
+static int ingest(dexsim_t h, const int64_t* ids, int k, int what, void* stream) {
+  NEED_BOUND(h);
+  if (k == 0) return DEXSIM_OK;
+  if (!ids || k < 0) return fail(DEXSIM_ERR_ARG, "indexed set: bad env_ids");
+  k_ingest<<<dim3((k + 63) / 64), 64, 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, ids, k, what, h->NS, h->N);
+  LAUNCH_CHECK();
+  return launch_publish(h, 0, 0, stream);
+}
+int dexsim_set_dof_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream) { return ingest(h, env_ids, k, 0, stream); }
+int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream) { return ingest(h, env_ids, k, 1, stream); }
+
+static int launch_stage(dexsim_t h, int stage, void* stream) {
+  switch (stage) {
+    case DEXSIM_STAGE_DYNAMICS: k_dynamics<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, 0, h->NS); break;
+    case DEXSIM_STAGE_SOLVE: k_solve<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, 0, 1, h->NS); break;
+    case DEXSIM_STAGE_PUBLISH: k_publish<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST: k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST + 100: k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
+    case DEXSIM_STAGE_RESET:
+      k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 0, h->NS, h->N);
+      k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 1, h->NS, h->N);
+      break;
+    case DEXSIM_STAGE_FINALIZE:
+      k_finalize<<<1, 64, 0, (hipStream_t)stream>>>(h->api, h->d_params, h->N);
+      k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters);
+      break;
+    default: return fail(DEXSIM_ERR_ARG, "unknown stage");
+  }
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
+
+int dexsim_run_stage(dexsim_t h, int stage, void* stream) {
+  NEED_BOUND(h);
+  return launch_stage(h, stage, stream);
+}
+
+int dexsim_time_stage(dexsim_t h, int stage, int launches, void* stream, float* mean_us) {
+  NEED_BOUND(h);
+  if (launches <= 0 || !mean_us) return fail(DEXSIM_ERR_ARG, "dexsim_time_stage: bad argument");
+  double total = 0;
+  for (int i = 0; i < launches; i++) {
+    // keep the state physical: every timed solve is preceded by its (untimed) dynamics launch
+    if (stage == DEXSIM_STAGE_SOLVE) { int rc = launch_stage(h, DEXSIM_STAGE_DYNAMICS, stream); if (rc) return rc; }
+    HIP_TRY(hipEventRecord(h->ev0, (hipStream_t)stream));
+    int rc = launch_stage(h, stage, stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev1, (hipStream_t)stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    total += ms;
+  }
+  *mean_us = (float)(total * 1000.0 / launches);
+  return DEXSIM_OK;
+}
+
+const char* dexsim_error_string(int code) {
+  switch (code) {
+    case DEXSIM_OK: return "ok";
+    case DEXSIM_ERR_ARG: return "invalid argument";
+    case DEXSIM_ERR_NOT_BOUND: return "buffers not bound";
+    case DEXSIM_ERR_HIP: return "HIP runtime error";
+    case DEXSIM_ERR_NO_DEVICE: return "no usable HIP device";
+    case DEXSIM_ERR_LAYOUT: return "arena layout error";
+    default: return "unknown error";
+  }
+}
+
+const char* dexsim_last_error(void) { return g_last_error.c_str(); }
+
+} // extern "C"

@@ -1,0 +1,209 @@
+// dexsim_device.h -- device-side data layout and small math for the gfx950 kernels.
+//
+// Data layout in HBM: every per-env quantity is one *field* of the arena, stored SoA as [row][env]
+// (env fastest).  A wavefront of 64 lanes = 64 consecutive envs, so every load/store of a field row is one
+// fully coalesced 256-byte transaction.  Wave-uniform constants (hand model, config) live in one DevParams
+// block that the compiler reads through the scalar cache (s_load), costing no VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/dexsim.h"
+
+// (type, name, rows) -- the arena contract.  Rows * num_envs 4-byte words each.
+#define DEXSIM_FIELDS(X)                                                                                    \
+  /* physics state (replaces PhysX-owned state behind gym.acquire_*_tensor) */                              \
+  X(float, q, 26) X(float, qd, 26) X(float, targets, 26)                                                    \
+  X(float, box_pos, 3) X(float, box_quat, 4) X(float, box_lin, 3) X(float, box_ang, 3)                      \
+  X(float, box_mass, 1) X(float, box_mu, 1)                                                                 \
+  /* compact L1 state read by the fused post-physics kernel */                                              \
+  X(float, site_pose, 77) X(float, hand_vel, 6) X(float, cforce, 51) X(float, cf5, 15)                      \
+  /* dynamics -> contact-solve interface (one sub-step) */                                                  \
+  X(float, jframe, 156) X(float, ufree, 32) X(float, fac_sinv, 21) X(float, fac_finv, 50)                   \
+  X(float, fac_g, 120) X(int, ncontact, 1) X(float, cgeom, DEXSIM_KMAX * 8) X(int, ccode, DEXSIM_KMAX)      \
+  X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, cbias, DEXSIM_KMAX)                                         \
+  /* L2 state (ActionProcessor / ObservationEncoder / task / RewardCalculator / TerminationManager) */      \
+  X(float, active_prev_targets, 18) X(float, active_rule_targets, 18) X(float, prev_actions, 18)            \
+  X(float, actions, 18) X(float, prev_dof_pos, 26)                                                          \
+  X(float, contact_duration_steps, 5) X(float, prev_contact_binary, 5) X(int, episode_step, 1)              \
+  X(int, success_duration_steps, 1) X(int, success_conditions_met, 1) X(int, current_stage, 1)              \
+  X(int, just2, 1) X(int, just3, 1) X(float, time_in_stage, 1) X(float, stage_contact_duration, 1)          \
+  X(float, initial_box_pos, 3)                                                                              \
+  X(float, prev_finger_dof_vel, 20) X(float, prev_hand_vel, 3) X(float, prev_hand_ang_vel, 3)               \
+  X(int, prev_contacts, 5)                                                                                  \
+  X(int, episode_success, 1) X(int, episode_failure, 1) X(int, success_reason, DEXSIM_NUM_SUCC)             \
+  X(int, failure_reason, DEXSIM_NUM_FAIL) X(int, crit_success, DEXSIM_NUM_SUCC)                             \
+  X(int, crit_failure, DEXSIM_NUM_FAIL) X(int, term_success, 1) X(int, term_failure, 1)                     \
+  X(int, term_timeout, 1)                                                                                   \
+  X(float, obs_all, DEXSIM_OBS_ALL_DIM) X(float, rew_comp, DEXSIM_NUM_REWROWS) X(float, rew, 1)             \
+  X(int, reset_flag, 1) X(int, reset_count, 1)
+
+struct Arena {
+#define X(type, name, rows) type* name;
+  DEXSIM_FIELDS(X)
+#undef X
+};
+
+#define CROW_W 28 /* words per contact row: t6 jf4 St6 Fj4 d3 rxd3 Dinv pad */
+
+struct DevParams {
+  DexSimConfig cfg;
+  DexHandModel model;
+  float h;           // sub-step
+  float box_inv_I_k; // 6 / size^2 : inv inertia of a solid cube = box_inv_I_k / mass
+};
+
+// counters block (ints): reduction scratch + device-side control flags
+#define CNT_ANY_RESET 0   /* set by the post kernel when some env must reset this step          */
+#define CNT_SUCC 1        /* [NUM_SUCC] */
+#define CNT_FAIL 2        /* [NUM_FAIL] */
+#define CNT_TERM_SUCCESS 8
+#define CNT_TERM_FAILURE 9
+#define CNT_TERM_TIMEOUT 10
+#define CNT_NUM_RESETS 11
+#define CNT_CONTACTS 12   /* sum of active contacts in the last solver invocation */
+#define CNT_PHYS_STEPS 13
+#define CNT_CONSECUTIVE 14 /* persistent */
+#define CNT_RC_FIRST 15    /* persistent: RewardCalculator lazy prev-state init pending */
+
+// ------------------------------------------------------------------------------------------------- math
+struct V3 { float x, y, z; };
+struct Q4 { float x, y, z, w; };
+struct S6 { float xx, yy, zz, xy, xz, yz; }; // symmetric 3x3
+struct M3 { float m[9]; };
+
+#define DI __device__ __forceinline__
+
+DI V3 v3(float x, float y, float z) { return {x, y, z}; }
+DI V3 v3p(const float* p) { return {p[0], p[1], p[2]}; }
+DI V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DI V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DI V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+DI V3& operator+=(V3& a, V3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+DI V3& operator-=(V3& a, V3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+DI float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DI V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DI float norm(V3 a) { return sqrtf(dot(a, a)); }
+DI float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+DI Q4 q4p(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+DI Q4 qmul(Q4 a, Q4 b) { // xyzw Hamilton product
+  return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+          a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+DI Q4 qconj(Q4 a) { return {-a.x, -a.y, -a.z, a.w}; }
+DI M3 q2mat(Q4 q) {
+  M3 R;
+  float x = q.x, y = q.y, z = q.z, w = q.w;
+  R.m[0] = 1 - 2 * (y * y + z * z); R.m[1] = 2 * (x * y - z * w); R.m[2] = 2 * (x * z + y * w);
+  R.m[3] = 2 * (x * y + z * w); R.m[4] = 1 - 2 * (x * x + z * z); R.m[5] = 2 * (y * z - x * w);
+  R.m[6] = 2 * (x * z - y * w); R.m[7] = 2 * (y * z + x * w); R.m[8] = 1 - 2 * (x * x + y * y);
+  return R;
+}
+DI V3 mul(const M3& R, V3 v) {
+  return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+          R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+DI V3 mulT(const M3& R, V3 v) {
+  return {R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z, R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z,
+          R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z};
+}
+// quat_rotate_inverse(q, v) = v(2w^2-1) - 2w (q_v x v) + 2 q_v (q_v . v)
+DI V3 qrot_inv(Q4 q, V3 v) {
+  V3 qv = {q.x, q.y, q.z};
+  V3 c = cross(qv, v);
+  float d = dot(qv, v), s = 2 * q.w * q.w - 1;
+  return {v.x * s - 2 * q.w * c.x + 2 * qv.x * d, v.y * s - 2 * q.w * c.y + 2 * qv.y * d,
+          v.z * s - 2 * q.w * c.z + 2 * qv.z * d};
+}
+DI V3 mul(S6 I, V3 v) {
+  return {I.xx * v.x + I.xy * v.y + I.xz * v.z, I.xy * v.x + I.yy * v.y + I.yz * v.z,
+          I.xz * v.x + I.yz * v.y + I.zz * v.z};
+}
+DI S6 operator+(S6 a, S6 b) { return {a.xx + b.xx, a.yy + b.yy, a.zz + b.zz, a.xy + b.xy, a.xz + b.xz, a.yz + b.yz}; }
+// R * I_local * R^T for a symmetric local inertia
+DI S6 rotate_inertia(const M3& R, const float* s /*xx yy zz xy xz yz*/) {
+  float Il[9] = {s[0], s[3], s[4], s[3], s[1], s[5], s[4], s[5], s[2]};
+  float T[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) T[3 * r + k] = R.m[3 * r] * Il[k] + R.m[3 * r + 1] * Il[3 + k] + R.m[3 * r + 2] * Il[6 + k];
+  auto e = [&](int r, int k) { return T[3 * r] * R.m[3 * k] + T[3 * r + 1] * R.m[3 * k + 1] + T[3 * r + 2] * R.m[3 * k + 2]; };
+  return {e(0, 0), e(1, 1), e(2, 2), e(0, 1), e(0, 2), e(1, 2)};
+}
+// parallel-axis term  m (|d|^2 E - d d^T)
+DI S6 pa(float m, V3 d) {
+  float dd = dot(d, d);
+  return {m * (dd - d.x * d.x), m * (dd - d.y * d.y), m * (dd - d.z * d.z), -m * d.x * d.y, -m * d.x * d.z, -m * d.y * d.z};
+}
+
+struct Comp { float m; V3 c; S6 I; };
+// a <- a (+) b  (both with positive or zero mass; zero+zero stays at a)
+DI void comp_add(Comp& a, const Comp& b) {
+  float m = a.m + b.m;
+  if (m <= 0.f) return;
+  float inv = 1.f / m;
+  V3 c = {(a.m * a.c.x + b.m * b.c.x) * inv, (a.m * a.c.y + b.m * b.c.y) * inv, (a.m * a.c.z + b.m * b.c.z) * inv};
+  S6 I = a.I + b.I + pa(a.m, a.c - c) + pa(b.m, b.c - c);
+  a.m = m; a.c = c; a.I = I;
+}
+
+// in-place inverse of an SPD n x n matrix (row-major full storage) through Cholesky; fully unrolled
+template <int n>
+DI void spd_inverse(float* A) {
+  float L[n * n];
+#pragma unroll
+  for (int i = 0; i < n; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = A[i * n + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+      if (i == j) L[i * n + i] = sqrtf(fmaxf(s, 1e-20f));
+      else L[i * n + j] = s / L[j * n + j];
+    }
+  float Li[n * n]; // inverse of L (lower)
+#pragma unroll
+  for (int c = 0; c < n; c++)
+#pragma unroll
+    for (int i = c; i < n; i++) {
+      float s = (i == c) ? 1.f : 0.f;
+#pragma unroll
+      for (int k = c; k < i; k++) s -= L[i * n + k] * Li[k * n + c];
+      Li[i * n + c] = s / L[i * n + i];
+    }
+#pragma unroll
+  for (int i = 0; i < n; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = i; k < n; k++) s += Li[k * n + i] * Li[k * n + j];
+      A[i * n + j] = s;
+      A[j * n + i] = s;
+    }
+}
+
+DI void tangent_basis(V3 n, V3& t1, V3& t2) {
+  V3 e = (fabsf(n.x) < 0.57735f) ? v3(1, 0, 0) : v3(0, 1, 0);
+  t1 = cross(e, n);
+  float l = norm(t1);
+  t1 = {t1.x / l, t1.y / l, t1.z / l};
+  t2 = cross(n, t1);
+}
+
+// Philox4x32-10 (device-side reset / domain-randomisation stream)
+DI void philox4x32(uint32_t out[4], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = c[i];
+}
+DI float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }

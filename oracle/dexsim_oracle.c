@@ -440,9 +440,9 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
   }
   real mu_hg = (real)0.5 * (m->hand_friction + cfg->ground_friction);
   real mu_hb = (real)0.5 * (m->hand_friction + e->box_mu);
-  /* capsule order: distal, middle, proximal links of fingers 0..4, then the palm */
+  /* capsule order: finger 0..4, each distal -> middle -> proximal, then the palm */
   for (int k = 0; k < DEXSIM_NCAP; k++) {
-    int c = k < 15 ? 3 + 3 * (k % 5) + (2 - k / 5) : k - 15;
+    int c = k < 15 ? 3 + 3 * (k / 3) + (2 - k % 3) : k - 15;
     int j = m->cap_parent[c];
     real r = m->cap_r[c];
     real l0[3] = {m->cap_p0[c][0], m->cap_p0[c][1], m->cap_p0[c][2]}, l1[3] = {m->cap_p1[c][0], m->cap_p1[c][1], m->cap_p1[c][2]};

@@ -1,0 +1,85 @@
+"""Adapter that drives the HIP kernels through the C-ABI with the same stage interface as oracle.Oracle,
+so that the golden replays and the oracle-parity tests run unchanged on the GPU."""
+import numpy as np
+import torch
+
+from dexrobot_isaac_amd import _abi
+from dexrobot_isaac_amd.core import DexSimCore
+
+CNT_ANY_RESET = 0
+
+
+class HipBackend:
+    def __init__(self, sim_cfg, model_struct, device="cuda:0"):
+        self.core = DexSimCore(sim_cfg, model_struct, device)
+        self.n = self.core.N
+        self._posted = False
+
+    # -- state exchange (SoA [rows][N] float64, like the oracle wrapper)
+    def set(self, name, value):
+        f = self.core.field(name)
+        v = np.broadcast_to(np.asarray(value, dtype=np.float64), tuple(f.shape))
+        f.copy_(torch.as_tensor(np.ascontiguousarray(v)).to(f.dtype))
+
+    def get(self, name):
+        return self.core.field(name).detach().cpu().numpy().astype(np.float64)
+
+    def obs_buf(self):
+        return self.core.obs_buf.detach().cpu().numpy()
+
+    def stats(self):
+        return self.core.stats.detach().cpu().numpy()
+
+    def set_reset_samples(self, s):
+        self.core.set_reset_samples(s)
+
+    def contacts(self, env):
+        k = int(self.get("ncontact")[0, env])
+        g = self.get("cgeom")[:, env].reshape(_abi.KMAX, 8)[:k]
+        code = self.get("ccode")[:, env][:k].astype(int)
+        out = np.zeros((k, 10))
+        out[:, :8] = g
+        out[:, 8] = code & 3
+        out[:, 9] = code >> 2
+        return out
+
+    # -- pipeline stages
+    def process_actions(self, actions, zero_targets=False):
+        self.core.process_actions(torch.as_tensor(np.ascontiguousarray(actions), dtype=torch.float32,
+                                                  device=self.core.device), zero_targets)
+
+    def compute_observations(self):
+        self.core.run_stage(_abi.STAGE["POST"] + 100)
+
+    def l2_step_no_reset(self):
+        if self._posted:
+            self.core.run_stage(_abi.STAGE["FINALIZE"])
+        self.core.run_stage(_abi.STAGE["POST"])
+        self._posted = True
+
+    def reset_flagged_no_physics(self):
+        self.core.counters[CNT_ANY_RESET] = 1
+        self.core.run_stage(_abi.STAGE["RESET"])
+
+    def substep(self, last=True):
+        self.core.run_stage(_abi.STAGE["DYNAMICS"])
+        self.core.run_stage(_abi.STAGE["SOLVE"])
+
+    def publish(self):
+        self.core.run_stage(_abi.STAGE["PUBLISH"])
+
+    def physics_step(self):
+        self.core.physics_step(False)
+
+    def step(self, actions):
+        self.core.step(torch.as_tensor(np.ascontiguousarray(actions), dtype=torch.float32, device=self.core.device))
+        torch.cuda.synchronize()
+        return (self.obs_buf(), self.core.rew_buf.cpu().numpy(), self.core.reset_buf.cpu().numpy())
+
+    def reset(self):
+        self.core.reset()
+        torch.cuda.synchronize()
+        return self.obs_buf()
+
+    def reset_idx(self, ids):
+        self.core.reset_idx(torch.as_tensor(np.asarray(ids, dtype=np.int64)))
