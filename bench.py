@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of random-action BlindGrasping at num_envs=4096 per GPU (BASELINE.json metric,
+configs[2] at N=1; configs[3] = the same sharded over N GPUs, weak scaling).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one env.step() for every env of the rank: action processing, one physics step (4 sub-steps of
+dynamics + PGS contact solve), fused obs/reward/termination, in-step resets and the reference's conditional
+extra physics step -- nothing is skipped.  Synthetic data: random actions 2*U(0,1)-1 (the law of the
+reference's random-action mode, dexhand_base.py:856), pre-generated in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(sim_cfg_factory, seconds_budget=20.0):
+    """The CPU oracle (scalar restatement of the same algorithm; 'port', not PhysX) on the host cores,
+    bounded sample of the same workload."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    n = 1024
+    sc, model = sim_cfg_factory(n)
+    best = None
+    avail = len(os.sched_getaffinity(0))
+    for cores in sorted({4, min(avail, 16)}):
+        o = Oracle(sc, model.to_struct(), threads=cores)
+        o.reset()
+        rng = np.random.default_rng(1234)
+        acts = [(2 * rng.random((n, 18)) - 1).astype(np.float32) for _ in range(4)]
+        o.step(acts[0])
+        t0, k = time.time(), 0
+        while time.time() - t0 < seconds_budget / 2 and k < 40:
+            o.step(acts[k % 4])
+            k += 1
+        v = n * k / (time.time() - t0)
+        if best is None or v > best["value"]:
+            best = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                    "sample": f"BlindGrasping N={n}, {k} control steps, random actions, oracle/dexsim_oracle.c with OpenMP"}
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--horizon", type=int, default=16, help="rollout length between RCCL gathers (gpus > 1)")
+    ap.add_argument("--dr", action="store_true", help="BASELINE config #5: per-env box mass/friction randomisation")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from dexrobot_isaac_amd import _abi
+    from dexrobot_isaac_amd.config import build_sim_config, default_cfg
+    from dexrobot_isaac_amd.core import DexSimCore
+    from dexrobot_isaac_amd.rollout import RolloutBuffer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    def factory(n):
+        cfg = default_cfg("BlindGrasping")
+        cfg["env"]["numEnvs"] = n
+        dr = {"mass": (0.05, 0.2), "friction": (0.5, 1.5), "seed": 4242 + rank} if args.dr else None
+        return build_sim_config(cfg, dr=dr)
+
+    N = args.num_envs
+    sc, model = factory(N)
+    sc.seed = 42 + rank                      # rank-local reset stream
+    core = DexSimCore(sc, model.to_struct(), device)
+    core.reset()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    n_act = 64                               # distinct pre-generated action batches, cycled
+    actions = 2.0 * torch.rand(n_act, N, 18, device=device, generator=gen) - 1.0
+    rollout = RolloutBuffer(args.horizon, N, sc.num_obs, device) if world > 1 else None
+
+    def run(k):
+        for i in range(k):
+            core.step(actions[i % n_act])
+            if rollout is not None:
+                rollout.add(core.obs_buf, core.rew_buf, core.reset_buf)
+                if rollout.full():
+                    rollout.gather()         # RCCL all-gather over xGMI, once per rollout
+
+    run(args.warmup)
+    resets0 = float(core.field("reset_count").sum().item())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    resets = float(core.field("reset_count").sum().item()) - resets0
+
+    if rank == 0:
+        total_envs = N * world
+        value = total_envs * args.steps / dt
+        # live per-kernel timing with HIP events on the launch stream (one launch = one sub-step of all envs)
+        kbar = float(core.stats[_abi.STAT["MEAN_CONTACTS"]].item())
+        t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)
+        t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)
+        t_post = core.time_stage(_abi.STAGE["POST"], 20)
+        t_pub = core.time_stage(_abi.STAGE["PUBLISH"], 20)
+        peak = 8000.0
+        b_solve = (256.0 + 60.0 * kbar) * N            # SURVEY.md §8d contact-solve bytes / env / invocation
+        b_dyn = (500.0 + 36.0 * kbar) * N              # state in, free velocity + manifold out
+        def roof(bytes_, us):
+            a = bytes_ / (us * 1e-6) / 1e9
+            return {"bound": "hbm", "achieved": a, "peak": peak, "unit": "GB/s", "frac": a / peak, "traffic": None}
+        r_solve = dict(roof(b_solve, t_solve), kernel="k_solve", avg_us=t_solve, mean_contacts=kbar)
+        r_dyn = dict(roof(b_dyn, t_dyn), kernel="k_dynamics", avg_us=t_dyn, mean_contacts=kbar)
+        step_bytes = 2560.0                            # SURVEY.md §8d whole env-step
+        out = {
+            "metric": "env-steps/sec BlindGrasping num_envs=4096 per MI355X (random actions)",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BlindGrasping num_envs=4096/GPU (BASELINE configs[2]; configs[3] when n_gpus>1)",
+                       "num_envs_per_gpu": N, "sim_dt": 0.01, "substeps": 4, "pgs_iterations": 16,
+                       "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
+                       "domain_randomisation": bool(args.dr)},
+            "resets_per_step": resets / args.steps,
+            "physics_steps_per_control_step": float(core.stats[_abi.STAT["PHYSICS_STEPS"]].item()),
+            "roofline": r_dyn if t_dyn >= t_solve else r_solve,
+            "roofline_contact_solve": r_solve,
+            "roofline_dynamics": r_dyn,
+            "roofline_whole_step": {"bound": "hbm", "achieved": step_bytes * value / world / 1e9, "peak": peak,
+                                    "unit": "GB/s", "frac": step_bytes * value / world / 1e9 / peak, "traffic": None},
+            "kernel_us": {"k_dynamics": t_dyn, "k_solve": t_solve, "k_post": t_post, "k_publish": t_pub},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(factory)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,7 +112,9 @@ def test_contact_manifold_matches_oracle():
     for e in range(n):
         co, ch = o.contacts(e), hb.contacts(e)
         assert co.shape == ch.shape
-        assert (co[:, 8:] == ch[:, 8:]).all()
+        assert (co[:, 8] == ch[:, 8]).all()                      # contact type
+        hand = co[:, 8] != 2
+        assert (co[hand, 9] == ch[hand, 9]).all()                # capsule id (undefined for box/ground)
         np.testing.assert_allclose(ch[:, :8], co[:, :8], atol=2e-6)
         total += len(co)
     assert total > 4 * n
