@@ -16,6 +16,8 @@ NUM_REWARD_TERMS = 26
 NUM_COMMON_REWARD_TERMS = 10
 REWROW_WEIGHTED, REWROW_TOTAL, REWROW_TERM_RAW, REWROW_TERM_W, NUM_REWROWS = 26, 52, 53, 56, 59
 NUM_SUCC, NUM_FAIL = 1, 5
+NUM_MASKS = 3 + NUM_SUCC + NUM_FAIL
+MASK_SUCCESS, MASK_FAILURE, MASK_TIMEOUT, MASK_SUCC_REASON, MASK_FAIL_REASON = 0, 1, 2, 3, 3 + NUM_SUCC
 STAT_WORDS = 64
 STAT = dict(SUCC_MEAN=0, FAIL_MEAN=4, SUCCESS_RATE=12, FAILURE_RATE=13, TIMEOUT_RATE=14,
             CONSECUTIVE_SUCCESSES=15, NUM_RESETS=16, PHYSICS_STEPS=17, MEAN_CONTACTS=18)
@@ -96,6 +98,7 @@ class DexSimBuffers(C.Structure):
         ("dof_state", C.c_void_p), ("root_state", C.c_void_p),
         ("rigid_body_states", C.c_void_p), ("contact_forces_all", C.c_void_p),
         ("full_dof_targets", C.c_void_p), ("reset_samples", C.c_void_p),
+        ("masks", C.c_void_p), ("raw_targets", C.c_void_p),
     ]
 
 

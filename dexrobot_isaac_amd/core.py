@@ -52,6 +52,8 @@ class DexSimCore:
         self.contact_forces_all = z(N, B, 3)
         self.full_dof_targets = z(N, _abi.NJ)
         self.reset_samples = None
+        self.masks = z(_abi.NUM_MASKS, N, dtype=torch.bool)
+        self.raw_targets = None
 
         self.h = C.c_void_p()
         check(self.lib.dexsim_create(C.byref(sim_cfg), C.byref(model_struct), dev_index, C.byref(self.h)), "create")
@@ -69,6 +71,8 @@ class DexSimCore:
         b.rigid_body_states, b.contact_forces_all = self.rigid_body_states.data_ptr(), self.contact_forces_all.data_ptr()
         b.full_dof_targets = self.full_dof_targets.data_ptr()
         b.reset_samples = self.reset_samples.data_ptr() if self.reset_samples is not None else None
+        b.masks = self.masks.data_ptr()
+        b.raw_targets = self.raw_targets.data_ptr() if self.raw_targets is not None else None
         check(self.lib.dexsim_bind(self.h, C.byref(b)), "bind")
 
     def _stream(self):
@@ -100,6 +104,20 @@ class DexSimCore:
             assert s.shape == (self.N, _abi.NRESET_SAMPLES)
             self.reset_samples = s
         self._bind()
+
+    def set_raw_targets(self, raw):
+        """(N, 18) output of a host-side custom action rule for the next process_actions; None -> built-in rule."""
+        if raw is None:
+            if self.raw_targets is not None:
+                self.raw_targets = None
+                self._bind()
+            return
+        first = self.raw_targets is None
+        if first:
+            self.raw_targets = torch.zeros(self.N, _abi.NACT, device=self.device)
+        self.raw_targets.copy_(raw)
+        if first:
+            self._bind()
 
     def _actions_ptr(self, actions):
         if actions is None:

@@ -210,6 +210,7 @@ int dexsim_bind(dexsim_t h, const DexSimBuffers* b) {
   h->api.dof_state = b->dof_state; h->api.root_state = b->root_state;
   h->api.rigid_body_states = b->rigid_body_states; h->api.contact_forces_all = b->contact_forces_all;
   h->api.full_dof_targets = b->full_dof_targets; h->api.reset_samples = b->reset_samples;
+  h->api.masks = b->masks; h->api.raw_targets = b->raw_targets;
   h->api.stats = b->stats; h->api.counters = b->counters;
   h->bound = true;
   return DEXSIM_OK;

@@ -116,6 +116,12 @@ enum {
 #define DEXSIM_FAIL_stage2_contact_failed  3
 #define DEXSIM_FAIL_stage3_grasp_lost      4
 #define DEXSIM_NUM_FAIL 5
+#define DEXSIM_MASK_SUCCESS 0
+#define DEXSIM_MASK_FAILURE 1
+#define DEXSIM_MASK_TIMEOUT 2
+#define DEXSIM_MASK_SUCC_REASON 3                       /* [NUM_SUCC] */
+#define DEXSIM_MASK_FAIL_REASON (3 + DEXSIM_NUM_SUCC)   /* [NUM_FAIL] */
+#define DEXSIM_NUM_MASKS (3 + DEXSIM_NUM_SUCC + DEXSIM_NUM_FAIL)
 
 /* global statistics block (device, 64 floats): written once per step by the finalize kernel.
  * termination_manager.py:164-185,259-266 (means / rates), :323-339 (consecutive successes). */
@@ -246,6 +252,12 @@ typedef struct DexSimBuffers {
   float*   contact_forces_all; /* (N, B, 3)   filled by dexsim_refresh_body_states only             */
   float*   full_dof_targets;   /* (N, 26)     ActionProcessor.full_dof_targets                      */
   float*   reset_samples;      /* (N, 29) uniforms in [0,1) or NULL -> device Philox stream         */
+  uint8_t* masks;              /* (DEXSIM_NUM_MASKS, N) bool rows, extras masks (step_processor.py:221-232,
+                                  termination_manager.py:246-256): success, failure, timeout,
+                                  success_reason[NUM_SUCC], failure_reason[NUM_FAIL]; may be NULL     */
+  float*   raw_targets;        /* (N, 18) or NULL: output of a host-side custom action rule
+                                  (ActionRules.set_action_rule, rules.py:211-224) replacing the built-in
+                                  position / position_delta rule; filters + coupling still run in-kernel */
 } DexSimBuffers;
 
 typedef struct DexSim* dexsim_t;
