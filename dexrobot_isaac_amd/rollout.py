@@ -41,14 +41,15 @@ class RolloutBuffer:
             return self.obs, self.rew, self.done
         R = dist.get_world_size()
         if self._g is None:
-            self._g = (torch.empty(R, self.T, self.N, self.O, device=self.device),
-                       torch.empty(R, self.T, self.N, device=self.device),
-                       torch.empty(R, self.T, self.N, dtype=torch.uint8, device=self.device))
-        go, gr, gd = self._g
-        dist.all_gather_into_tensor(go, self.obs)
-        dist.all_gather_into_tensor(gr, self.rew)
-        dist.all_gather_into_tensor(gd, self.done)
-        self.t = 0
+            # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept)
+            self._g = (torch.empty(R * self.T, self.N, self.O, device=self.device),
+                       torch.empty(R * self.T, self.N, device=self.device),
+                       torch.empty(R * self.T, self.N, dtype=torch.uint8, device=self.device))
         T, N, O = self.T, self.N, self.O
+        dist.all_gather_into_tensor(self._g[0], self.obs)
+        dist.all_gather_into_tensor(self._g[1], self.rew)
+        dist.all_gather_into_tensor(self._g[2], self.done)
+        go, gr, gd = self._g[0].view(R, T, N, O), self._g[1].view(R, T, N), self._g[2].view(R, T, N)
+        self.t = 0
         return (go.permute(1, 0, 2, 3).reshape(T, R * N, O), gr.permute(1, 0, 2).reshape(T, R * N),
                 gd.permute(1, 0, 2).reshape(T, R * N))

@@ -1,0 +1,148 @@
+"""Physics of the oracle (= the specification the HIP integrator implements).  There is no PhysX ground truth
+(parity vs PhysX: UNPINNED), so the oracle is checked against first principles:
+mass matrix / gravity / Coriolis against numerical differentiation of the kinematics, static equilibrium,
+resting contact, frictional pushing, and fp32-vs-fp64 agreement that sizes the GPU parity tolerances."""
+import numpy as np
+import pytest
+
+from dexrobot_isaac_amd.config import build_sim_config, default_cfg
+from oracle.oracle import Oracle
+
+
+def _mk(task="BlindGrasping", n=4, f64=False):
+    cfg = default_cfg(task)
+    cfg["env"]["numEnvs"] = n
+    sc, model = build_sim_config(cfg)
+    return Oracle(sc, model.to_struct(), f64=f64), model, sc
+
+
+def _numeric_mass_and_gravity(model, q, eps=1e-6):
+    m = model
+
+    def parent(j):
+        return -1 if j == 0 else (j - 1 if j < 6 else (5 if (j - 6) % 4 == 0 else j - 1))
+
+    def rodr(ax, a):
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+    def fk(q):
+        R, o = [None] * 26, [None] * 26
+        for j in range(26):
+            p = parent(j)
+            Rp, op = (m.spawn_rot, m.spawn_pos) if p < 0 else (R[p], o[p])
+            Rz, oj = Rp @ m.jRoff[j], op + Rp @ m.jpoff[j]
+            if m.jtype[j] == 0:
+                R[j], o[j] = Rz, oj + Rz @ m.jaxis[j] * q[j]
+            else:
+                R[j], o[j] = Rz @ rodr(m.jaxis[j], q[j]), oj
+        return np.array([o[j] + R[j] @ m.com[j] for j in range(26)]), R
+
+    def sym(s):
+        return np.array([[s[0], s[3], s[4]], [s[3], s[1], s[5]], [s[4], s[5], s[2]]])
+
+    c0, R0 = fk(q)
+    Jv, Jw = np.zeros((26, 3, 26)), np.zeros((26, 3, 26))
+    for k in range(26):
+        dq = np.zeros(26)
+        dq[k] = eps
+        c1, R1 = fk(q + dq)
+        c2, R2 = fk(q - dq)
+        Jv[:, :, k] = (c1 - c2) / (2 * eps)
+        for j in range(26):
+            dR = (R1[j] - R2[j]) / (2 * eps) @ R0[j].T
+            Jw[j, :, k] = [dR[2, 1], dR[0, 2], dR[1, 0]]
+    M = sum(m.mass[j] * Jv[j].T @ Jv[j] + Jw[j].T @ (R0[j] @ sym(m.inertia[j]) @ R0[j].T) @ Jw[j] for j in range(26))
+    V = lambda qq: float(np.sum(m.mass * 9.81 * fk(qq)[0][:, 2]))
+    g = np.array([(V(q + np.eye(26)[k] * eps) - V(q - np.eye(26)[k] * eps)) / (2 * eps) for k in range(26)])
+    return M, g
+
+
+def test_mass_matrix_gravity_coriolis_match_numerical_derivation():
+    o, model, _ = _mk(f64=True)
+    rng = np.random.default_rng(0)
+    q, qd = rng.uniform(-0.3, 0.6, 26), rng.uniform(-1, 1, 26)
+    M, b0 = o.mass_matrix(q, np.zeros(26))
+    Mn, gn = _numeric_mass_and_gravity(model, q)
+    assert np.abs(M - Mn).max() < 1e-7 and np.abs(M - M.T).max() == 0 and np.linalg.eigvalsh(M).min() > 0
+    assert np.abs(b0 - gn).max() < 1e-6
+    _, b = o.mass_matrix(q, qd)
+    e = 1e-5
+    Mof = lambda qq: o.mass_matrix(qq, np.zeros(26))[0]
+    Mdot = (Mof(q + e * qd) - Mof(q - e * qd)) / (2 * e)
+    dT = np.array([(qd @ Mof(q + np.eye(26)[k] * e) @ qd - qd @ Mof(q - np.eye(26)[k] * e) @ qd) / (2 * e) for k in range(26)])
+    assert np.abs((b - b0) - (Mdot @ qd - 0.5 * dT)).max() < 1e-8      # c(q, qd) = Mdot qd - 1/2 d(qd' M qd)/dq
+
+
+def test_hand_base_mount_is_90deg_about_y():
+    o, model, _ = _mk()
+    o.publish()
+    hp = o.get("site_pose")[:7, 0]
+    np.testing.assert_allclose(hp[:3], [0, 0, 0.5], atol=1e-7)                   # spawn (cfg initialHandPos)
+    np.testing.assert_allclose(hp[3:], [0, np.sqrt(0.5), 0, np.sqrt(0.5)], atol=1e-6)   # observation_encoder.py:1496-1503
+    tips = o.get("site_pose")[7:42, 0].reshape(5, 7)
+    assert (tips[1:, 2] < 0.4).all()                                             # fingers point down (-z)
+
+
+def test_static_equilibrium_and_resting_box():
+    o, _, sc = _mk(n=2)
+    z = np.zeros((2, 18), dtype=np.float32)
+    o.set("targets", 0.0)
+    for _ in range(100):
+        o.physics_step()
+    q, qd = o.get("q"), o.get("qd")
+    assert abs(q[2, 0] + 0.5268 * 9.81 / 10000) < 2e-5                          # ARTz sags by m g / kp
+    assert np.abs(qd).max() < 1e-4
+    bp, bl = o.get("box_pos"), o.get("box_lin")
+    assert abs(bp[2, 0] - (0.025 + sc.rest_offset)) < 1e-4 and np.abs(bl).max() < 1e-4
+    np.testing.assert_allclose(o.get("cforce")[48:51, 0], [0, 0, 0.1 * 9.81], atol=1e-3)   # ground reaction = m g
+    assert (o.get("ncontact")[0] == 4).all()
+
+
+def test_fingers_press_on_box():
+    """Lower the hand at the task's base speed limit (0.1 m/s) until the fingertips press on the box top: the
+    box must stay on the ground (no tunnelling either way), the ground reaction must carry the extra load, and the
+    distal links must report contact forces (the source of the obs path's contact_binary)."""
+    o, _, sc = _mk(n=1)
+    tg = np.zeros((26, 1))
+    for _ in range(300):
+        tg[2] = max(tg[2] - 0.001, -0.2445)      # ARTz target: middle fingertip sphere ~2 mm into the box top
+        o.set("targets", tg)
+        o.physics_step()
+    cf = o.get("cforce")[:, 0].reshape(17, 3)
+    distal = np.linalg.norm(cf[[2, 5, 8, 11, 14]], axis=1)
+    assert o.get("ncontact")[0, 0] > 4
+    assert distal.max() > 1.0 and distal.max() < 60.0          # ~ kp * penetration demand, not an explosion
+    assert abs(o.get("box_pos")[2, 0] - 0.0255) < 3e-3 and np.abs(o.get("box_lin")).max() < 0.05
+    tips = o.get("site_pose")[7:42, 0].reshape(5, 7)
+    assert tips[1:4, 2].min() > 0.05 + 0.007 - 4e-3             # tip spheres rest on the box top (z = 0.0505)
+    assert np.isfinite(o.get("q")).all() and np.abs(o.get("qd")).max() < 1.0
+
+
+def test_fp32_oracle_agrees_with_fp64_oracle():
+    """Sizes the GPU parity tolerance: a single control step of the fp32 oracle vs the fp64 oracle."""
+    o32, _, _ = _mk(n=16)
+    o64, _, _ = _mk(n=16, f64=True)
+    o32.reset()
+    o64.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        a = (2 * rng.random((16, 18)) - 1).astype(np.float32)
+        ob32, _, _ = o32.step(a)
+        ob64, _, _ = o64.step(a)
+    assert np.abs(ob32 - ob64).max() < 2e-3
+    assert np.median(np.abs(ob32 - ob64)) < 1e-6
+
+
+def test_philox_reset_stream_is_reproducible_and_uniform():
+    o, _, _ = _mk(n=512)
+    o.reset()
+    q = o.get("q")
+    box = o.get("initial_box_pos")
+    assert np.abs(box[0]).max() <= 0.02 + 1e-7 and np.abs(box[1]).max() <= 0.02 + 1e-7 and (box[2] == np.float32(0.027)).all()
+    assert abs(box[0].mean()) < 0.003 and box[0].std() > 0.009                  # U(-0.02, 0.02): std 0.0115
+    o2, _, _ = _mk(n=512)
+    o2.reset()
+    assert np.array_equal(o2.get("initial_box_pos"), box)                        # same (seed, env, reset_count) key
+    o2.reset()
+    assert not np.array_equal(o2.get("initial_box_pos"), box)                    # next reset_count -> new draw
