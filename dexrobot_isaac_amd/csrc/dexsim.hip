@@ -173,8 +173,16 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   hp.cfg = *cfg; hp.model = *model;
   hp.h = cfg->dt / (float)cfg->substeps;
   hp.box_inv_I_k = cfg->has_box ? 6.f / (cfg->box_size * cfg->box_size) : 0.f;
+  {
+    int k = 0;
+    for (int s = 0; s < cfg->n_obs_seg; s++)
+      for (int i = 0; i < cfg->obs_seg_len[s]; i++) hp.obs_col_row[k++] = cfg->obs_seg_off[s] + i;
+    for (; k < DEXSIM_OBS_ALL_DIM; k++) hp.obs_col_row[k] = 0;
+  }
   HIP_TRY(hipMalloc(&h->d_params, sizeof(DevParams)));
   HIP_TRY(hipMemcpy(h->d_params, &hp, sizeof(DevParams), hipMemcpyHostToDevice));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
   *out = h;
@@ -223,7 +231,28 @@ int dexsim_bind(dexsim_t h, const DexSimBuffers* b) {
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
 static int launch_publish(dexsim_t h, int gate, int full, void* stream) {
-  k_publish<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, gate, full, h->NS, h->N);
+  if (gate) k_publish<true><<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, full, h->NS, h->N);
+  else k_publish<false><<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, full, h->NS, h->N);
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
+
+// LDS budget of the contact-solve kernel: stage the rows of as many contacts as fit next to u_f and the impulses.
+// At <= 1 wavefront per CU (num_envs <= 64 * #CUs) the whole 160 KiB is this wave's to use.
+static int solve_kstage(const DexSim* h) { return h->NS <= 64 * 256 ? 6 : 2; }
+static size_t solve_lds_bytes(int kstage) { return (size_t)SOLVE_LDS_WORDS(kstage) * 64 * sizeof(float); }
+
+static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
+  const int ks = solve_kstage(h);
+  const size_t lds = solve_lds_bytes(ks);
+  if (gate) k_solve<true><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, ks, h->NS);
+  else k_solve<false><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, ks, h->NS);
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
+static int launch_dynamics(dexsim_t h, int gate, void* stream) {
+  if (gate) k_dynamics<true><<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, h->NS);
+  else k_dynamics<false><<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, h->NS);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
@@ -253,10 +282,10 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
   NEED_BOUND(h);
   for (int s = 0; s < h->cfg.substeps; s++) {
-    k_dynamics<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, gate_on_reset, h->NS);
-    LAUNCH_CHECK();
-    k_solve<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, gate_on_reset, s == h->cfg.substeps - 1, h->NS);
-    LAUNCH_CHECK();
+    int rc = launch_dynamics(h, gate_on_reset, stream);
+    if (rc) return rc;
+    rc = launch_solve(h, gate_on_reset, s == h->cfg.substeps - 1, stream);
+    if (rc) return rc;
   }
   return launch_publish(h, gate_on_reset, 0, stream);
 }
@@ -335,9 +364,9 @@ int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, voi
 
 static int launch_stage(dexsim_t h, int stage, void* stream) {
   switch (stage) {
-    case DEXSIM_STAGE_DYNAMICS: k_dynamics<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, 0, h->NS); break;
-    case DEXSIM_STAGE_SOLVE: k_solve<<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, 0, 1, h->NS); break;
-    case DEXSIM_STAGE_PUBLISH: k_publish<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
+    case DEXSIM_STAGE_DYNAMICS: return launch_dynamics(h, 0, stream);
+    case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);
+    case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
     case DEXSIM_STAGE_POST: k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_POST + 100: k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:

@@ -50,6 +50,7 @@ struct DevParams {
   DexHandModel model;
   float h;           // sub-step
   float box_inv_I_k; // 6 / size^2 : inv inertia of a solid cube = box_inv_I_k / mass
+  int obs_col_row[DEXSIM_OBS_ALL_DIM]; // obs_buf column -> obs_all row (flattened policy_observation_keys)
 };
 
 // counters block (ints): reduction scratch + device-side control flags
