@@ -292,7 +292,7 @@ int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
 
 int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
   NEED_BOUND(h);
-  k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, h->NS, h->N);
+  k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, h->NS, h->N);
   LAUNCH_CHECK();
   if (obs_only) return DEXSIM_OK;
   // reset_idx(nonzero(reset_buf)) incl. the extra physics step for ALL envs (step_processor.py:109-111,
@@ -367,8 +367,8 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_DYNAMICS: return launch_dynamics(h, 0, stream);
     case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
-    case DEXSIM_STAGE_POST: k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
-    case DEXSIM_STAGE_POST + 100: k_post<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:
       k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 0, h->NS, h->N);
       k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 1, h->NS, h->N);
