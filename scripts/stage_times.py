@@ -14,10 +14,14 @@ from dexrobot_isaac_amd.core import DexSimCore  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--num-envs", type=int, nargs="+", default=[4096])
 ap.add_argument("--launches", type=int, default=50)
+ap.add_argument("--iters", type=int, nargs="+", default=[16])
+ap.add_argument("--task", default="BlindGrasping")
 args = ap.parse_args()
-for n in args.num_envs:
-    cfg = default_cfg("BlindGrasping")
+import itertools
+for n, iters in itertools.product(args.num_envs, args.iters):
+    cfg = default_cfg(args.task)
     cfg["env"]["numEnvs"] = n
+    cfg["sim"]["physx"]["num_position_iterations"] = iters
     sc, model = build_sim_config(cfg)
     core = DexSimCore(sc, model.to_struct(), "cuda:0")
     core.reset()
@@ -33,5 +37,5 @@ for n in args.num_envs:
         core.step(a)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 100
-    print(f"N={n}: us/launch {out}  step {dt * 1e6:.1f} us  -> {n / dt / 1e6:.2f} M env-steps/s  contacts {float(core.stats[18]):.2f}")
+    print(f"N={n} iters={iters}: us/launch {out}  step {dt * 1e6:.1f} us  -> {n / dt / 1e6:.2f} M env-steps/s  contacts {float(core.stats[18]):.2f}")
     core.close()

@@ -174,3 +174,42 @@ def test_body_states_and_indexed_setters():
     core.set_dof_state_indexed(torch.tensor([1, 65]))
     after = hb.get("q")
     assert np.allclose(after[:, [1, 65]], 0.123) and np.allclose(np.delete(after, [1, 65], 1), np.delete(before, [1, 65], 1))
+
+
+def test_make_env_product_path_on_gpu():
+    """The product's own surface (make_env -> DexHandEnv -> C-ABI) on the GPU, against the oracle driven with the
+    same actions and the same Philox reset stream; plus the extras / obs_dict contract."""
+    import torch
+    from dexrobot_isaac_amd import default_cfg, make_env
+    from oracle.py_backend import OracleCore
+    n = 96
+    cfg = default_cfg("BlindGrasping")
+    cfg["env"]["episodeLength"] = 12
+    env = make_env("BlindGrasping", n, "cuda:0", "cuda:0", 0, cfg=cfg)
+    ref = make_env("BlindGrasping", n, "cpu", "cpu", 0, cfg=cfg, _core_factory=OracleCore)
+    o_g, o_r = env.reset(), ref.reset()
+    assert o_g.is_cuda and o_g.shape == (n, 158)
+    np.testing.assert_allclose(o_g.cpu().numpy(), o_r.numpy(), atol=2e-4)
+    g = torch.Generator().manual_seed(5)
+    for t in range(16):
+        a = 2 * torch.rand(n, 18, generator=g) - 1
+        og, rg, dg, ig = env.step(a.cuda())
+        orr, rr, dr, ir = ref.step(a)
+        np.testing.assert_allclose(og.cpu().numpy(), orr.numpy(), atol=2e-3)
+        np.testing.assert_allclose(rg.cpu().numpy(), rr.numpy(), atol=2e-2, rtol=1e-4)
+        assert (dg.cpu() == dr).all() and dg.dtype == torch.bool
+        assert float(ig["timeout_rate"]) == float(ir["timeout_rate"])
+        for k in ("success", "failure", "timeout", "failure_reason_hitting_ground"):
+            assert (ig[k].cpu() == ir[k]).all()
+        assert (ig["episode_length"].cpu() == ir["episode_length"]).all()
+    assert int(env.reset_buf.sum()) + int(env.episode_step_count.sum()) > 0
+    assert float(ig["reward_components"]["termination_timeout_penalty_weighted"].min()) <= 0
+    od = env.get_observations_dict()
+    cat = torch.cat([od[k] for k in env.task_cfg["policy_observation_keys"]], dim=1)
+    assert torch.allclose(cat, env.obs_buf)
+    rbs = env.rigid_body_states
+    assert rbs.shape == (n, 38, 13) and torch.allclose(rbs[:, 6, :7], od["hand_pose"], atol=1e-6)
+    assert env.contact_forces.shape == (n, 5, 3)
+    env.reset_idx(torch.tensor([3, 5], device="cuda:0"))
+    assert env.episode_step_count[[3, 5]].tolist() == [0, 0]
+    env.close()
