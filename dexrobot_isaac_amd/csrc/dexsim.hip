@@ -231,8 +231,8 @@ int dexsim_bind(dexsim_t h, const DexSimBuffers* b) {
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
 static int launch_publish(dexsim_t h, int gate, int full, void* stream) {
-  if (gate) k_publish<true><<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, full, h->NS, h->N);
-  else k_publish<false><<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, full, h->NS, h->N);
+  if (gate) k_publish<true><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, full, h->NS, h->N);
+  else k_publish<false><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, full, h->NS, h->N);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
@@ -251,8 +251,8 @@ static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
   return DEXSIM_OK;
 }
 static int launch_dynamics(dexsim_t h, int gate, void* stream) {
-  if (gate) k_dynamics<true><<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, h->NS);
-  else k_dynamics<false><<<GRID(h)>>>(h->arena, h->d_params, h->api.counters, h->NS);
+  if (gate) k_dynamics<true><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->NS);
+  else k_dynamics<false><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->NS);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
