@@ -183,6 +183,8 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   HIP_TRY(hipMemcpy(h->d_params, &hp, sizeof(DevParams), hipMemcpyHostToDevice));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
   *out = h;
@@ -250,6 +252,13 @@ static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
+static int launch_substep(dexsim_t h, int gate, int last, void* stream) {
+  const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
+  if (gate) k_substep<true><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, h->NS);
+  else k_substep<false><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, h->NS);
+  LAUNCH_CHECK();
+  return DEXSIM_OK;
+}
 static int launch_dynamics(dexsim_t h, int gate, void* stream) {
   if (gate) k_dynamics<true><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->NS);
   else k_dynamics<false><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->NS);
@@ -282,9 +291,7 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
   NEED_BOUND(h);
   for (int s = 0; s < h->cfg.substeps; s++) {
-    int rc = launch_dynamics(h, gate_on_reset, stream);
-    if (rc) return rc;
-    rc = launch_solve(h, gate_on_reset, s == h->cfg.substeps - 1, stream);
+    int rc = launch_substep(h, gate_on_reset, s == h->cfg.substeps - 1, stream);   // fused dynamics + solve + integrate
     if (rc) return rc;
   }
   return launch_publish(h, gate_on_reset, 0, stream);
@@ -367,6 +374,7 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_DYNAMICS: return launch_dynamics(h, 0, stream);
     case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
+    case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, stream);
     case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:

@@ -329,12 +329,13 @@ int dexsim_set_dof_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void
 int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream);
 
 /* Test / profiling hooks: run one pipeline stage on the bound buffers. */
-#define DEXSIM_STAGE_DYNAMICS 0  /* FK + CRBA + bias + factorisation + narrowphase + row build      */
-#define DEXSIM_STAGE_SOLVE    1  /* PGS contact-impulse solve + integrate                           */
+#define DEXSIM_STAGE_DYNAMICS 0  /* FK + CRBA + bias + factorisation + narrowphase + row build (stand-alone kernel) */
+#define DEXSIM_STAGE_SOLVE    1  /* PGS contact-impulse solve + integrate (stand-alone kernel)      */
 #define DEXSIM_STAGE_PUBLISH  2  /* FK of sites, AoS dof_state/root publication                     */
 #define DEXSIM_STAGE_POST     3  /* fused obs + FSM + termination + reward                          */
 #define DEXSIM_STAGE_RESET    4  /* masked reset of envs whose reset_buf is set                     */
 #define DEXSIM_STAGE_FINALIZE 5  /* statistics                                                      */
+#define DEXSIM_STAGE_SUBSTEP  6  /* production sub-step: DYNAMICS + SOLVE fused in one launch       */
 int dexsim_run_stage(dexsim_t h, int stage, void* stream);
 
 /* Time `launches` back-to-back launches of one stage with hipEvents on `stream`; returns the mean

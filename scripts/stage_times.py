@@ -29,7 +29,7 @@ for n, iters in itertools.product(args.num_envs, args.iters):
     for _ in range(20):
         core.step(a)
     torch.cuda.synchronize()
-    out = {k: round(core.time_stage(v, args.launches), 2) for k, v in _abi.STAGE.items() if k != "FINALIZE"}
+    out = {k: round(core.time_stage(v, args.launches), 2) for k, v in _abi.STAGE.items() if k not in ("FINALIZE",)}
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()

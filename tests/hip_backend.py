@@ -10,7 +10,8 @@ CNT_ANY_RESET = 0
 
 
 class HipBackend:
-    def __init__(self, sim_cfg, model_struct, device="cuda:0"):
+    def __init__(self, sim_cfg, model_struct, device="cuda:0", fused=True):
+        self.fused = fused        # True: production k_substep; False: stand-alone k_dynamics + k_solve
         self.core = DexSimCore(sim_cfg, model_struct, device)
         self.n = self.core.N
         self._posted = False
@@ -62,8 +63,11 @@ class HipBackend:
         self.core.run_stage(_abi.STAGE["RESET"])
 
     def substep(self, last=True):
-        self.core.run_stage(_abi.STAGE["DYNAMICS"])
-        self.core.run_stage(_abi.STAGE["SOLVE"])
+        if self.fused:
+            self.core.run_stage(_abi.STAGE["SUBSTEP"])
+        else:
+            self.core.run_stage(_abi.STAGE["DYNAMICS"])
+            self.core.run_stage(_abi.STAGE["SOLVE"])
 
     def publish(self):
         self.core.run_stage(_abi.STAGE["PUBLISH"])

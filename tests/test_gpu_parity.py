@@ -53,8 +53,9 @@ def _random_state(rng, model, n, near_box=True):
                 box_lin=rng.normal(0, 0.05, (3, n)), box_ang=rng.normal(0, 0.3, (3, n)))
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["k_substep", "k_dynamics+k_solve"])
 @pytest.mark.parametrize("task", ["BlindGrasping", "BaseTask"])
-def test_teacher_forced_substep_matches_oracle(task):
+def test_teacher_forced_substep_matches_oracle(task, fused):
     """One sub-step (dynamics + contact solve + integrate) from identical state.
     Tolerance: 2e-4 abs on q / box pose, 2e-3 on velocities (PGS amplifies fp32 roundoff of the two
     factorisations: dense Cholesky in the oracle vs Schur-complement blocks on the GPU), contact count exact."""
@@ -63,7 +64,7 @@ def test_teacher_forced_substep_matches_oracle(task):
     n = 256
     sc, model = _mk(task, n)
     ms = model.to_struct()
-    o, hb = Oracle(sc, ms), HipBackend(sc, ms)
+    o, hb = Oracle(sc, ms), HipBackend(sc, ms, fused=fused)
     rng = np.random.default_rng(5)
     st = _random_state(rng, model, n)
     for k, v in st.items():
