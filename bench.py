@@ -122,19 +122,33 @@ def main():
         value = total_envs * args.steps / dt
         # live per-kernel timing with HIP events on the launch stream (one launch = one sub-step of all envs)
         kbar = float(core.stats[_abi.STAT["MEAN_CONTACTS"]].item())
-        t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)
+        t_sub = core.time_stage(_abi.STAGE["SUBSTEP"], 50)     # production: dynamics + solve + integrate fused
+        t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)     # the same sweeps as a stand-alone kernel
         t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)
         t_post = core.time_stage(_abi.STAGE["POST"], 20)
         t_pub = core.time_stage(_abi.STAGE["PUBLISH"], 20)
         peak = 8000.0
-        b_solve = (256.0 + 60.0 * kbar) * N            # SURVEY.md §8d contact-solve bytes / env / invocation
-        b_dyn = (500.0 + 36.0 * kbar) * N              # state in, free velocity + manifold out
-        def roof(bytes_, us):
+        # algorithmic HBM bytes per env per launch
+        b_sub = (632.0 + 51.0) * N                     # q, qd, targets, box in; q, qd, box out; cforce on 1 of 4
+        b_solve = (256.0 + 60.0 * kbar) * N
+        b_dyn = (500.0 + 36.0 * kbar) * N
+        pmc = {}
+        try:                                           # HBM traffic from the separate rocprofv3 --pmc passes
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        except Exception:
+            pass
+
+        def roof(kernel, bytes_, us):
             a = bytes_ / (us * 1e-6) / 1e9
-            return {"bound": "hbm", "achieved": a, "peak": peak, "unit": "GB/s", "frac": a / peak, "traffic": None}
-        r_solve = dict(roof(b_solve, t_solve), kernel="k_solve", avg_us=t_solve, mean_contacts=kbar)
-        r_dyn = dict(roof(b_dyn, t_dyn), kernel="k_dynamics", avg_us=t_dyn, mean_contacts=kbar)
-        step_bytes = 2560.0                            # SURVEY.md §8d whole env-step
+            tr = None
+            rec = pmc.get(kernel)
+            if rec and int(rec.get("num_envs", -1)) == N:
+                # gfx950: FETCH_SIZE tallies 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); counters are in KB
+                tr = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0
+            return {"bound": "hbm", "achieved": a, "peak": peak, "unit": "GB/s", "frac": a / peak, "traffic": tr,
+                    "kernel": kernel, "avg_us": us, "algorithmic_bytes": bytes_, "mean_contacts": kbar}
+
+        step_bytes = 2560.0                            # SURVEY.md section 8d whole env-step
         out = {
             "metric": "env-steps/sec BlindGrasping num_envs=4096 per MI355X (random actions)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,13 +159,12 @@ def main():
                        "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
                        "domain_randomisation": bool(args.dr)},
             "resets_per_step": resets / args.steps,
-            "physics_steps_per_control_step": float(core.stats[_abi.STAT["PHYSICS_STEPS"]].item()),
-            "roofline": r_dyn if t_dyn >= t_solve else r_solve,
-            "roofline_contact_solve": r_solve,
-            "roofline_dynamics": r_dyn,
+            "roofline": roof("k_substep", b_sub, t_sub),
+            "roofline_contact_solve": roof("k_solve", b_solve, t_solve),
+            "roofline_dynamics": roof("k_dynamics", b_dyn, t_dyn),
             "roofline_whole_step": {"bound": "hbm", "achieved": step_bytes * value / world / 1e9, "peak": peak,
                                     "unit": "GB/s", "frac": step_bytes * value / world / 1e9 / peak, "traffic": None},
-            "kernel_us": {"k_dynamics": t_dyn, "k_solve": t_solve, "k_post": t_post, "k_publish": t_pub},
+            "kernel_us": {"k_substep": t_sub, "k_dynamics": t_dyn, "k_solve": t_solve, "k_post": t_post, "k_publish": t_pub},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(factory)
