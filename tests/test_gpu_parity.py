@@ -214,3 +214,27 @@ def test_make_env_product_path_on_gpu():
     env.reset_idx(torch.tensor([3, 5], device="cuda:0"))
     assert env.episode_step_count[[3, 5]].tolist() == [0, 0]
     env.close()
+
+
+def test_long_random_rollout_stays_finite_and_resets_cycle():
+    """BASELINE configs[2] shape at reduced N: 700 random-action control steps; state must stay finite, joints inside
+    their limits, the box on or above the ground, and the episode machinery must cycle (stage-1 failures at t = 4 s)."""
+    import torch
+    from dexrobot_isaac_amd import make_env
+    n = 1024
+    env = make_env("BlindGrasping", n, "cuda:0", "cuda:0", 0)
+    env.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    resets = 0
+    for t in range(700):
+        obs, rew, done, info = env.step(2 * torch.rand(n, 18, device="cuda:0", generator=g) - 1)
+        resets += int(done.sum())
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    q = env.dof_pos
+    lo, hi = env.dof_props[:, 4], env.dof_props[:, 5]
+    assert (q >= lo - 1e-5).all() and (q <= hi + 1e-5).all()
+    box_z = env.actor_root_state_tensor[:, 1, 2]
+    assert (box_z > 0.015).all() and (box_z < 0.6).all()
+    assert resets >= 2 * n                       # every env failed the pre-grasp check at least twice
+    assert float(info["failure_rate"]) >= 0.0 and int(env.episode_step_count.max()) <= 499
+    env.close()
