@@ -252,10 +252,15 @@ static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
-static int launch_substep(dexsim_t h, int gate, int last, void* stream) {
+// nsub sub-steps (+ optional publication) in one launch
+static int launch_substep(dexsim_t h, int gate, int nsub, int last_is_final, int publish, void* stream) {
   const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
-  if (gate) k_substep<true><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, h->NS);
-  else k_substep<false><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, h->NS);
+  if (gate)
+    k_substep<true><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nsub,
+                                                                                last_is_final, publish, h->NS, h->N);
+  else
+    k_substep<false><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nsub,
+                                                                                 last_is_final, publish, h->NS, h->N);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
@@ -290,11 +295,8 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 
 int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
   NEED_BOUND(h);
-  for (int s = 0; s < h->cfg.substeps; s++) {
-    int rc = launch_substep(h, gate_on_reset, s == h->cfg.substeps - 1, stream);   // fused dynamics + solve + integrate
-    if (rc) return rc;
-  }
-  return launch_publish(h, gate_on_reset, 0, stream);
+  // the whole sim.dt (all sub-steps: dynamics + contact solve + integrate) and the publication in ONE launch
+  return launch_substep(h, gate_on_reset, h->cfg.substeps, 1, 1, stream);
 }
 
 int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
@@ -374,7 +376,7 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_DYNAMICS: return launch_dynamics(h, 0, stream);
     case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
-    case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, stream);
+    case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, 1, 0, stream);
     case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:
