@@ -222,6 +222,7 @@ int dexsim_bind(dexsim_t h, const DexSimBuffers* b) {
   h->api.full_dof_targets = b->full_dof_targets; h->api.reset_samples = b->reset_samples;
   h->api.masks = b->masks; h->api.raw_targets = b->raw_targets;
   h->api.stats = b->stats; h->api.counters = b->counters;
+  HIP_TRY(hipMemcpy(&h->d_params->arena, &h->arena, sizeof(Arena), hipMemcpyHostToDevice));
   h->bound = true;
   return DEXSIM_OK;
 }
@@ -256,10 +257,10 @@ static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
 static int launch_substep(dexsim_t h, int gate, int nsub, int last_is_final, int publish, void* stream) {
   const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
   if (gate)
-    k_substep<true><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nsub,
+    k_substep<true><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->api, h->d_params, h->api.counters, nsub,
                                                                                 last_is_final, publish, h->NS, h->N);
   else
-    k_substep<false><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nsub,
+    k_substep<false><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->api, h->d_params, h->api.counters, nsub,
                                                                                  last_is_final, publish, h->NS, h->N);
   LAUNCH_CHECK();
   return DEXSIM_OK;

@@ -51,6 +51,8 @@ struct DevParams {
   float h;           // sub-step
   float box_inv_I_k; // 6 / size^2 : inv inertia of a solid cube = box_inv_I_k / mass
   int obs_col_row[DEXSIM_OBS_ALL_DIM]; // obs_buf column -> obs_all row (flattened policy_observation_keys)
+  Arena arena;       // field pointers (filled by dexsim_bind): kernels with long live ranges read them on demand
+                     // through the scalar cache instead of pinning 114 SGPRs of by-value kernel arguments
 };
 
 // counters block (ints): reduction scratch + device-side control flags
