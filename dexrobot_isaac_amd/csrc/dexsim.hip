@@ -183,8 +183,10 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   HIP_TRY(hipMemcpy(h->d_params, &hp, sizeof(DevParams), hipMemcpyHostToDevice));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
   *out = h;
@@ -253,15 +255,15 @@ static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
-// nsub sub-steps (+ optional publication) in one launch
-static int launch_substep(dexsim_t h, int gate, int nsub, int last_is_final, int publish, void* stream) {
+// one fused sub-step; `last` adds the contact-force accumulation and the publication
+static int launch_substep(dexsim_t h, int gate, int last, void* stream) {
   const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
-  if (gate)
-    k_substep<true><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->api, h->d_params, h->api.counters, nsub,
-                                                                                last_is_final, publish, h->NS, h->N);
-  else
-    k_substep<false><<<dim3(h->NS / 64), dim3(384), lds, (hipStream_t)stream>>>(h->api, h->d_params, h->api.counters, nsub,
-                                                                                 last_is_final, publish, h->NS, h->N);
+  const dim3 grid(h->NS / 64), block(384);
+  hipStream_t st = (hipStream_t)stream;
+  if (gate && last) k_substep<true, true><<<grid, block, lds, st>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
+  else if (gate) k_substep<true, false><<<grid, block, lds, st>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
+  else if (last) k_substep<false, true><<<grid, block, lds, st>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
+  else k_substep<false, false><<<grid, block, lds, st>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
@@ -296,8 +298,12 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 
 int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
   NEED_BOUND(h);
-  // the whole sim.dt (all sub-steps: dynamics + contact solve + integrate) and the publication in ONE launch
-  return launch_substep(h, gate_on_reset, h->cfg.substeps, 1, 1, stream);
+  // sim.dt = `substeps` fused launches (dynamics + contact solve + integrate); the last one also publishes
+  for (int s = 0; s < h->cfg.substeps; s++) {
+    int rc = launch_substep(h, gate_on_reset, s == h->cfg.substeps - 1, stream);
+    if (rc) return rc;
+  }
+  return DEXSIM_OK;
 }
 
 int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
@@ -377,7 +383,7 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_DYNAMICS: return launch_dynamics(h, 0, stream);
     case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
-    case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, 1, 0, stream);
+    case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, stream);
     case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:
