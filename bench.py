@@ -90,13 +90,20 @@ def main():
     actions = 2.0 * torch.rand(n_act, N, 18, device=device, generator=gen) - 1.0
     rollout = RolloutBuffer(args.horizon, N, sc.num_obs, device) if world > 1 else None
 
+    pending = []
+
     def run(k):
         for i in range(k):
             core.step(actions[i % n_act])
             if rollout is not None:
                 rollout.add(core.obs_buf, core.rew_buf, core.reset_buf)
                 if rollout.full():
-                    rollout.gather()         # RCCL all-gather over xGMI, once per rollout
+                    # RCCL all-gather over xGMI, once per rollout, overlapped with the next rollout's simulation
+                    pending.append(rollout.gather_async())
+                    if len(pending) > 1:
+                        pending.pop(0)()     # the previous rollout's gather must have landed by now
+        while pending:
+            pending.pop(0)()
 
     run(args.warmup)
     resets0 = float(core.field("reset_count").sum().item())

@@ -37,8 +37,12 @@ def _worker(rank, world, port, out_dir):
         buf.add(obs, rew, done)
         local.append((obs.clone(), rew.clone(), done.clone()))
     assert buf.full()
-    obs_g, rew_g, done_g = buf.gather()
+    handle = buf.gather_async()                # collectives in flight; the env keeps stepping into the other slot
     assert buf.t == 0
+    for t in range(2):
+        obs, rew, done, _ = env.step(2 * torch.rand(N, 18, generator=g) - 1)
+        buf.add(obs, rew, done)
+    obs_g, rew_g, done_g = handle()
     assert obs_g.shape == (T, world * N, env.num_observations) and rew_g.shape == (T, world * N)
     for t in range(T):                                    # env index = rank * N + local index
         assert torch.equal(obs_g[t, rank * N:(rank + 1) * N], local[t][0])

@@ -238,3 +238,77 @@ def test_long_random_rollout_stays_finite_and_resets_cycle():
     assert resets >= 2 * n                       # every env failed the pre-grasp check at least twice
     assert float(info["failure_rate"]) >= 0.0 and int(env.episode_step_count.max()) <= 499
     env.close()
+
+
+def test_domain_randomisation_stress_config5():
+    """BASELINE configs[4]: per-env box mass / friction randomisation (new capability; ranges are this build's choice).
+    The device Philox draw must equal the oracle's, masses must show up as ground reaction m*g, and the run stays finite."""
+    import torch
+    from dexrobot_isaac_amd import make_env
+    from oracle.oracle import Oracle
+    n = 512
+    dr = {"mass": (0.05, 0.2), "friction": (0.5, 1.5), "seed": 4242}
+    env = make_env("BlindGrasping", n, "cuda:0", "cuda:0", 0, domain_randomisation=dr)
+    core = env._core
+    mass, mu = core.field("box_mass")[0].cpu().numpy(), core.field("box_mu")[0].cpu().numpy()
+    assert 0.05 <= mass.min() and mass.max() <= 0.2 and mass.std() > 0.03
+    assert 0.5 <= mu.min() and mu.max() <= 1.5 and mu.std() > 0.2
+    sc, model = build_sim_config(env.cfg, dr=dr)
+    o = Oracle(sc, model.to_struct())
+    np.testing.assert_array_equal(o.get("box_mass")[0].astype(np.float32), mass)
+    env.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for _ in range(60):
+        obs, rew, done, _ = env.step(0.2 * (2 * torch.rand(n, 18, device="cuda:0", generator=g) - 1))
+    assert torch.isfinite(obs).all()
+    fz = core.field("cforce")[3 * 16 + 2].cpu().numpy()          # ground reaction on the resting boxes
+    rest = np.abs(core.field("box_lin").cpu().numpy()).max(axis=0) < 1e-3
+    assert rest.mean() > 0.9
+    np.testing.assert_allclose(fz[rest], 9.81 * mass[rest], rtol=2e-2)
+    env.close()
+
+
+def test_action_sweep_like_reference_harness():
+    """The reference's smoke procedure (examples/dexhand_test.py:1470-1584, 1707-1782) as an automated test:
+    BaseTask, position control, every finger action swept -1 -> 1 -> -1 over 100 steps (base actions 0 -> -1 -> 1 -> 0,
+    scaled 0.5); coupled joints must move together, r_f_joint3_1 must stay at 0 and the hand must come back to its
+    initial pose within 0.1 rad."""
+    import torch
+    from dexrobot_isaac_amd import default_cfg, make_env
+    cfg = default_cfg("BaseTask")
+    cfg["task"]["controlMode"] = "position"
+    cfg["env"]["episodeLength"] = 5000
+    env = make_env("BaseTask", 2, "cuda:0", "cuda:0", 0, cfg=cfg)
+    env.reset()
+    a = torch.zeros(2, 18, device="cuda:0")
+    a[:, 6:] = -1.0
+    for _ in range(60):                                           # settle at the closed pose
+        env.step(a)
+    q0 = env.dof_pos.clone()
+    moved = torch.zeros(26, device="cuda:0")
+    for idx in range(12):
+        for s in range(100):
+            a[:, :6] = 0.0
+            a[:, 6:] = -1.0
+            b = idx % 6
+            bv = -(s / 24.0) if s < 25 else (-1.0 + 2.0 * (s - 25) / 49.0 if s < 75 else 1.0 - (s - 75) / 24.0)
+            fv = -1.0 + 2.0 * s / 49.0 if s < 50 else 1.0 - 2.0 * (s - 50) / 49.0
+            a[:, b] = 0.5 * bv
+            a[:, 6 + idx] = fv
+            env.step(a)
+            d = (env.dof_pos[0] - q0[0]).abs()
+            moved = torch.maximum(moved, d)
+            if idx == 2 and s == 49:                              # th_dip drives joints 1_3 and 1_4 together
+                assert abs(float(env.dof_pos[0, 8] - env.dof_pos[0, 9])) < 0.05 and float(d[8]) > 0.5
+            if idx == 3 and s == 49:                              # ff_spr: 5_1 = 2 x (2_1, 4_1); 3_1 fixed
+                q = env.dof_pos[0]
+                assert abs(float(q[10] - q[18])) < 0.02 and abs(float(q[22] - 2 * q[10])) < 0.04 and float(q[10]) > 0.2
+    assert float(moved[14]) < 1e-3                                # r_f_joint3_1 never leaves 0
+    assert (moved[[6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25]] > 0.15).all()   # every other finger DOF moved
+    for _ in range(60):
+        a[:, :6] = 0.0
+        a[:, 6:] = -1.0
+        env.step(a)
+    assert float((env.dof_pos[0] - q0[0]).abs().max()) < 0.1      # "Hand returned close to initial position"
+    assert torch.isfinite(env.obs_buf).all()
+    env.close()
