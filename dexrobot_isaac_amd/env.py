@@ -186,7 +186,7 @@ class DexHandEnv:
     """Vectorised DexHand environment on one MI355X (one process per GPU; shard envs across ranks)."""
 
     def __init__(self, cfg, task_name, rl_device, sim_device, graphics_device_id=0, headless=True, force_render=False,
-                 video_config=None, domain_randomisation=None, _core_factory=None):
+                 video_config=None, domain_randomisation=None, hand_model=None, _core_factory=None):
         self.cfg = cfg
         self.env_cfg, self.task_cfg, self.sim_cfg = cfg["env"], cfg["task"], cfg["sim"]
         self.video_config = video_config
@@ -214,7 +214,9 @@ class DexHandEnv:
         self.clip_actions = self.env_cfg.get("clipActions", np.inf)
         self.seed(cfg["train"]["seed"])
 
-        self._sim_cfg, self.model = build_sim_config(cfg, dr=domain_randomisation)
+        # hand_model: a HandModel, e.g. dexrobot_isaac_amd.mjcf.load_mjcf(<dexhand021_right_simplified_floating.xml>);
+        # None = the authored stand-in (the reference's MJCF submodule is absent offline)
+        self._sim_cfg, self.model = build_sim_config(cfg, model=hand_model, dr=domain_randomisation)
         self._model_struct = self.model.to_struct()
         if _core_factory is None:
             from .core import DexSimCore
