@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Diagnostic: builds libdexsim with -DDEXSIM_PROFILE_PHASES into a scratch path and prints where a sub-step's cycles go
+(per wave, s_memtime at the phase boundaries).  The product library is never built with this flag."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dexrobot_isaac_amd import _abi, _lib  # noqa: E402
+from dexrobot_isaac_amd.build import CSRC  # noqa: E402
+
+out = os.path.join(ROOT, "gpurun_out", "libdexsim_prof.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-DDEXSIM_PROFILE_PHASES",
+                       "-o", out, os.path.join(CSRC, "dexsim.hip")], cwd=CSRC)
+_lib.LIB_PATH = out
+from dexrobot_isaac_amd.config import build_sim_config, default_cfg  # noqa: E402
+from dexrobot_isaac_amd.core import DexSimCore  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = default_cfg("BlindGrasping")
+cfg["env"]["numEnvs"] = n
+sc, model = build_sim_config(cfg)
+core = DexSimCore(sc, model.to_struct(), "cuda:0")
+core.reset()
+a = 2 * torch.rand(n, 18, device="cuda:0") - 1
+for _ in range(10):
+    core.step(a)
+core.run_stage(_abi.STAGE["SUBSTEP"])
+torch.cuda.synchronize()
+crow = core.field("crow").view(torch.int32).cpu().numpy()      # stamps of lane 0 of every block: rows wv*8 + k
+names = ["base chain", "phase1 fingers|palm", "phase2 schur|narrow", "phase3 rows", "phase4 sweeps", "phase5 integrate", "publish"]
+lanes = np.arange(0, n, 64)
+print(f"N={n}: cycles since kernel start at each boundary, median over {len(lanes)} workgroups (s_memtime @100 MHz ticks x?)")
+for wv in range(6):
+    st = np.array([[crow[wv * 8 + k, e] for k in range(7)] for e in lanes])
+    med = np.median(st, axis=0)
+    print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))

