@@ -179,6 +179,15 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
       for (int i = 0; i < cfg->obs_seg_len[s]; i++) hp.obs_col_row[k++] = cfg->obs_seg_off[s] + i;
     for (; k < DEXSIM_OBS_ALL_DIM; k++) hp.obs_col_row[k] = 0;
   }
+  for (int j = 0; j < DEXSIM_NJ; j++) {
+    JC& c = hp.jc[j];
+    std::memset(&c, 0, sizeof c);
+    for (int i = 0; i < 4; i++) c.qoff[i] = model->jqoff[j][i];
+    for (int i = 0; i < 3; i++) { c.poff[i] = model->jpoff[j][i]; c.axis[i] = model->jaxis[j][i]; c.com[i] = model->com[j][i]; }
+    for (int i = 0; i < 6; i++) c.inertia[i] = model->inertia[j][i];
+    c.mass = model->mass[j]; c.kp = model->kp[j]; c.kd = model->kd[j]; c.armature = model->armature[j];
+    c.lo = model->lo[j]; c.hi = model->hi[j];
+  }
   HIP_TRY(hipMalloc(&h->d_params, sizeof(DevParams)));
   HIP_TRY(hipMemcpy(h->d_params, &hp, sizeof(DevParams), hipMemcpyHostToDevice));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -45,12 +45,22 @@ struct Arena {
 
 #define CROW_W 28 /* words per contact row: t6 jf4 St6 Fj4 d3 rxd3 Dinv pad */
 
+// per-joint constants packed as one 128-byte record: a wave fetches everything it needs about joint j with two
+// s_load_dwordx16 instead of ~12 scattered scalar loads (the base-chain walk was scalar-load-latency bound)
+struct JC {
+  float qoff[4], poff[3], axis[3], com[3], inertia[6];
+  float mass, kp, kd, armature, lo, hi;
+  float pad[7];
+};
+static_assert(sizeof(JC) == 128, "JC must be 128 bytes");
+
 struct DevParams {
   DexSimConfig cfg;
   DexHandModel model;
   float h;           // sub-step
   float box_inv_I_k; // 6 / size^2 : inv inertia of a solid cube = box_inv_I_k / mass
   int obs_col_row[DEXSIM_OBS_ALL_DIM]; // obs_buf column -> obs_all row (flattened policy_observation_keys)
+  JC jc[DEXSIM_NJ];  // packed copy of the per-joint model constants
   Arena arena;       // field pointers (filled by dexsim_bind): kernels with long live ranges read them on demand
                      // through the scalar cache instead of pinning 114 SGPRs of by-value kernel arguments
 };
