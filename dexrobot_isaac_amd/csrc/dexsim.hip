@@ -326,18 +326,15 @@ int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
   LAUNCH_CHECK();
   int rc = dexsim_physics_step(h, 1, stream);
   if (rc) return rc;
-  k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 1, h->NS, h->N);
-  LAUNCH_CHECK();
-  k_finalize<<<1, 64, 0, (hipStream_t)stream>>>(h->api, h->d_params, h->N);
+  // phase 1 of the masked reset; its first thread also finalises the step statistics (k_finalize folded in)
+  k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 3, h->NS, h->N);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
 
 int dexsim_step(dexsim_t h, const float* actions, void* stream) {
   NEED_BOUND(h);
-  k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters);
-  LAUNCH_CHECK();
-  int rc = dexsim_process_actions(h, actions, 0, stream);
+  int rc = dexsim_process_actions(h, actions, 0, stream);   // also clears the per-step device flags
   if (rc) return rc;
   rc = dexsim_physics_step(h, 0, stream);
   if (rc) return rc;
