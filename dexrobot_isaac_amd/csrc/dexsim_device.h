@@ -79,6 +79,8 @@ struct DevParams {
 #define CNT_RC_FIRST 15    /* persistent: RewardCalculator lazy prev-state init pending */
 
 // ------------------------------------------------------------------------------------------------- math
+typedef float f2 __attribute__((ext_vector_type(2)));   // maps onto the gfx950 packed-FP32 VALU ops
+
 struct V3 { float x, y, z; };
 struct Q4 { float x, y, z, w; };
 struct S6 { float xx, yy, zz, xy, xz, yz; }; // symmetric 3x3

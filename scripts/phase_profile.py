@@ -15,7 +15,7 @@ from dexrobot_isaac_amd.build import CSRC  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "libdexsim_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-DDEXSIM_PROFILE_PHASES",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17", "-DDEXSIM_PROFILE_PHASES",
                        "-o", out, os.path.join(CSRC, "dexsim.hip")], cwd=CSRC)
 _lib.LIB_PATH = out
 from dexrobot_isaac_amd.config import build_sim_config, default_cfg  # noqa: E402
