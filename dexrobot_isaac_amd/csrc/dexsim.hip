@@ -196,6 +196,8 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_physics4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_physics4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
   *out = h;
@@ -307,7 +309,15 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 
 int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
   NEED_BOUND(h);
-  // sim.dt = `substeps` fused launches (dynamics + contact solve + integrate); the last one also publishes
+  if (h->cfg.substeps == 4) {   // the reference's setting: the whole sim.dt in one launch
+    const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
+    const dim3 grid(h->NS / 64), block(384);
+    if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
+    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
+    LAUNCH_CHECK();
+    return DEXSIM_OK;
+  }
+  // other sub-step counts: `substeps` fused launches (dynamics + contact solve + integrate); the last one also publishes
   for (int s = 0; s < h->cfg.substeps; s++) {
     int rc = launch_substep(h, gate_on_reset, s == h->cfg.substeps - 1, stream);
     if (rc) return rc;

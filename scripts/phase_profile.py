@@ -40,3 +40,15 @@ for wv in range(6):
     st = np.array([[crow[wv * 8 + k, e] for k in range(7)] for e in lanes])
     med = np.median(st, axis=0)
     print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))
+
+# k_post: stamps after the per-wave body, the barrier, the obs_all flush and the obs_buf flush
+core.run_stage(_abi.STAGE["POST"])
+torch.cuda.synchronize()
+crow = core.field("crow").view(torch.int32).cpu().numpy()
+pn = ["body", "barrier", "obs_all flush", "obs_buf flush"]
+for wv in range(4):
+    st = np.array([[crow[wv * 8 + k, e] for k in range(4)] for e in lanes])
+    print(f"k_post wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(pn, np.median(st, axis=0))))
+st = np.array([[crow[32 + k, e] for k in range(7)] for e in lanes])
+print("k_post body (wave 0): " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(
+    ["loads issued", "proprio+contacts", "task obs+FSM", "termination", "reward terms", "reward/mask stores", "stats"], np.median(st, axis=0))))
