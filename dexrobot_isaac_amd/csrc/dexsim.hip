@@ -307,13 +307,14 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
   return DEXSIM_OK;
 }
 
-int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
-  NEED_BOUND(h);
+// tail != 0 (gated launch of the step path only): the launch also applies phase 1 of the in-step reset and finalises
+// the step statistics, so that a control step is k_actions, k_physics4, k_post, k_physics4<gated> and nothing else
+static int physics_step(dexsim_t h, int gate_on_reset, int tail, void* stream) {
   if (h->cfg.substeps == 4) {   // the reference's setting: the whole sim.dt in one launch
     const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
     const dim3 grid(h->NS / 64), block(384);
-    if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
-    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
+    if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, tail, h->NS, h->N);
+    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N);
     LAUNCH_CHECK();
     return DEXSIM_OK;
   }
@@ -325,16 +326,23 @@ int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
   return DEXSIM_OK;
 }
 
+int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
+  NEED_BOUND(h);
+  return physics_step(h, gate_on_reset, 0, stream);
+}
+
 int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
   NEED_BOUND(h);
-  k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, h->NS, h->N);
+  const int fused = h->cfg.substeps == 4 && !obs_only;
+  k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, fused, h->NS, h->N);
   LAUNCH_CHECK();
   if (obs_only) return DEXSIM_OK;
   // reset_idx(nonzero(reset_buf)) incl. the extra physics step for ALL envs (step_processor.py:109-111,
   // reset_manager.py:180), gated on the device-side flag instead of torch.any() on the host
+  if (fused) return physics_step(h, 1, 1, stream);   // phase 0 ran inside k_post, phase 1 + statistics run in the gated launch
   k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 0, h->NS, h->N);
   LAUNCH_CHECK();
-  int rc = dexsim_physics_step(h, 1, stream);
+  int rc = physics_step(h, 1, 0, stream);
   if (rc) return rc;
   // phase 1 of the masked reset; its first thread also finalises the step statistics (k_finalize folded in)
   k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 3, h->NS, h->N);
@@ -400,8 +408,8 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
     case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, stream);
-    case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N); break;
-    case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:
       k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 0, h->NS, h->N);
       k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 1, h->NS, h->N);
