@@ -6,7 +6,8 @@ import os
 from . import _abi
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdexsim.so")
+# DEXSIM_LIB_PATH: diagnostics only (A/B of kernel variants, the phase-stamp build); it still has to be a libdexsim build
+LIB_PATH = os.environ.get("DEXSIM_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdexsim.so")
 
 
 class DexSimError(RuntimeError):
