@@ -408,6 +408,7 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
     case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, stream);
+    case DEXSIM_STAGE_PHYSICS: return physics_step(h, 0, 0, stream);
     case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:

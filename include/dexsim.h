@@ -335,7 +335,8 @@ int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, voi
 #define DEXSIM_STAGE_POST     3  /* fused obs + FSM + termination + reward                          */
 #define DEXSIM_STAGE_RESET    4  /* masked reset of envs whose reset_buf is set                     */
 #define DEXSIM_STAGE_FINALIZE 5  /* statistics                                                      */
-#define DEXSIM_STAGE_SUBSTEP  6  /* production sub-step: DYNAMICS + SOLVE fused in one launch       */
+#define DEXSIM_STAGE_SUBSTEP  6  /* one sub-step (DYNAMICS + SOLVE + integration + publication) as its own launch */
+#define DEXSIM_STAGE_PHYSICS  7  /* production physics step: all `substeps` of a sim.dt (one launch when substeps == 4) */
 int dexsim_run_stage(dexsim_t h, int stage, void* stream);
 
 /* Time `launches` back-to-back launches of one stage with hipEvents on `stream`; returns the mean

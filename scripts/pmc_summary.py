@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 outputs of scripts/profile_round.sh into the committed summaries:
+   <dst>/kernel_stats.csv (the --stats table), <dst>/pmc_summary.csv (mean FETCH_SIZE / WRITE_SIZE per launch, KB, raw)
+   and profiles/pmc_latest.json (what bench.py reads for roofline.traffic)."""
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+import pandas as pd
+
+src, dst = sys.argv[1], sys.argv[2]
+num_envs = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z_0-9:]+)(<[^(]*>)?\(", name + "(")
+    base = m.group(1) if m else name
+    tpl = m.group(2) or "" if m else ""
+    return base + tpl if base.startswith("k_") else base[:48]
+
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+rows = {}
+for which in ("fetch", "write"):
+    f = glob.glob(os.path.join(src, which, "**", "*counter_collection.csv"), recursive=True)
+    if not f:
+        continue
+    d = pd.read_csv(f[0])
+    d["k"] = d["Kernel_Name"].map(short)
+    for k, v in d.groupby("k")["Counter_Value"].mean().items():
+        rows.setdefault(k, {})[which + "_kb"] = float(v)
+    for k, v in d.groupby("k")["Counter_Value"].size().items():
+        rows.setdefault(k, {})["launches_" + which] = int(v)
+pd.DataFrame.from_dict(rows, orient="index").sort_index().to_csv(os.path.join(dst, "pmc_summary.csv"))
+latest = {}
+for k, r in rows.items():
+    if not k.startswith("k_"):
+        continue
+    base = re.sub(r"<.*", "", k)
+    gated = "<true" in k
+    if gated:
+        continue                      # the device-gated launches are no-ops unless an env reset
+    rec = latest.setdefault(base, {"num_envs": num_envs, "fetch_kb": 0.0, "write_kb": 0.0, "variants": 0})
+    rec["fetch_kb"] += r.get("fetch_kb", 0.0)
+    rec["write_kb"] += r.get("write_kb", 0.0)
+    rec["variants"] += 1
+for rec in latest.values():               # template variants of one kernel: mean over variants
+    rec["fetch_kb"] /= rec["variants"]
+    rec["write_kb"] /= rec["variants"]
+    del rec["variants"]
+json.dump(latest, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(latest, indent=1))
