@@ -182,8 +182,12 @@ def main():
             # so all episodes time out in the same control step and the conditional second physics step of
             # reset_manager.py:180 runs once per ~300 steps.  In training the episodes de-synchronise and some env
             # resets in (almost) every control step; this run staggers the episode clocks to show that regime.
-            es = core.field("episode_step")
-            es.copy_(torch.randint(0, int(sc.episode_length) - 2, es.shape, device=device, generator=gen).to(es.dtype))
+            # (random actions end every episode through the stage-1 pre-grasp check at t = 4 s = 200 control steps, so the
+            # stage clock and the episode clock are staggered together)
+            es, tis = core.field("episode_step"), core.field("time_in_stage")
+            k = torch.randint(0, 199, es.shape, device=device, generator=gen)
+            es.copy_(k.to(es.dtype))
+            tis.copy_(k.to(tis.dtype) * float(sc.control_dt))
             run(50)
             r0 = float(core.field("reset_count").sum().item())
             torch.cuda.synchronize()

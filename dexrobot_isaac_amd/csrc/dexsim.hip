@@ -2,6 +2,8 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared -o libdexsim.so dexsim.hip
 // No torch types, no CUDA shims, no dual back-end: this file only targets CDNA4 through HIP.
+#include <cmath>
+#include <algorithm>
 #include "dexsim_device.h"
 
 #include <cstdio>
@@ -173,6 +175,17 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   hp.cfg = *cfg; hp.model = *model;
   hp.h = cfg->dt / (float)cfg->substeps;
   hp.box_inv_I_k = cfg->has_box ? 6.f / (cfg->box_size * cfg->box_size) : 0.f;
+  {   // hand-level broadphase radius: chain of joint offsets from the palm to the capsule's joint + capsule extent + radius
+    auto len3 = [](const float* v) { return std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); };
+    double reach = 0.0;
+    for (int c = 0; c < DEXSIM_NCAP; c++) {
+      const int j = model->cap_parent[c];
+      double d = std::max(len3(model->cap_p0[c]), len3(model->cap_p1[c])) + model->cap_r[c];
+      if (j >= 6) for (int l = 6 + 4 * ((j - 6) / 4); l <= j; l++) d += len3(model->jpoff[l]);
+      reach = std::max(reach, d);
+    }
+    hp.hand_reach = (float)(reach * 1.001 + 1e-4);
+  }
   {
     int k = 0;
     for (int s = 0; s < cfg->n_obs_seg; s++)
@@ -196,6 +209,7 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_post), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_physics4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_physics4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipEventCreate(&h->ev0));
@@ -334,7 +348,7 @@ int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
 int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
   NEED_BOUND(h);
   const int fused = h->cfg.substeps == 4 && !obs_only;
-  k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, fused, h->NS, h->N);
+  k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, fused, h->NS, h->N);
   LAUNCH_CHECK();
   if (obs_only) return DEXSIM_OK;
   // reset_idx(nonzero(reset_buf)) incl. the extra physics step for ALL envs (step_processor.py:109-111,
@@ -409,8 +423,8 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
     case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, stream);
     case DEXSIM_STAGE_PHYSICS: return physics_step(h, 0, 0, stream);
-    case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
-    case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(256), 0, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, 0, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
+    case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:
       k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 0, h->NS, h->N);
       k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 1, h->NS, h->N);

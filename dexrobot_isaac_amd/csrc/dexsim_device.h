@@ -59,6 +59,8 @@ struct DevParams {
   DexHandModel model;
   float h;           // sub-step
   float box_inv_I_k; // 6 / size^2 : inv inertia of a solid cube = box_inv_I_k / mass
+  float hand_reach;  // bound on |x - o5| over every point x of every hand capsule, for any joint configuration
+                     // (o5 = origin of the palm joint frame): the hand-level broadphase of k_substep
   int obs_col_row[DEXSIM_OBS_ALL_DIM]; // obs_buf column -> obs_all row (flattened policy_observation_keys)
   JC jc[DEXSIM_NJ];  // packed copy of the per-joint model constants
   Arena arena;       // field pointers (filled by dexsim_bind): kernels with long live ranges read them on demand

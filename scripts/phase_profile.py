@@ -41,14 +41,24 @@ for wv in range(6):
     med = np.median(st, axis=0)
     print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))
 
-# k_post: stamps after the per-wave body, the barrier, the obs_all flush and the obs_buf flush
+# k_post: per-wave stamps after phase A (helper tasks / wave-0 loads), phase B (wave-0 logic), the row flush and the
+# obs_buf flush; then wave 0's logic split (relative to the start of phase B)
 core.run_stage(_abi.STAGE["POST"])
 torch.cuda.synchronize()
 crow = core.field("crow").view(torch.int32).cpu().numpy()
-pn = ["body", "barrier", "obs_all flush", "obs_buf flush"]
-for wv in range(4):
+pn = ["phase A", "phase B", "row flush", "obs_buf flush"]
+for wv in range(8):
     st = np.array([[crow[wv * 8 + k, e] for k in range(4)] for e in lanes])
     print(f"k_post wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(pn, np.median(st, axis=0))))
-st = np.array([[crow[32 + k, e] for k in range(7)] for e in lanes])
-print("k_post body (wave 0): " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(
-    ["loads issued", "proprio+contacts", "task obs+FSM", "termination", "reward terms", "reward/mask stores", "stats"], np.median(st, axis=0))))
+st = np.array([[crow[32 + k, e] for k in range(2, 7)] for e in lanes])
+print("k_post logic (wave 0, from phase B start): " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(
+    ["task obs+FSM", "termination", "reward terms", "reward table", "stats"], np.median(st, axis=0))))
+
+# the production launch: four bodies back to back (stamps are relative to each body's own start)
+core.run_stage(_abi.STAGE["PHYSICS"])
+torch.cuda.synchronize()
+crow = core.field("crow").view(torch.int32).cpu().numpy()
+for b in range(4):
+    for wv in (0, 4, 5):
+        st = np.array([[crow[64 * (b + 1) + wv * 8 + k, e] for k in range(7 if b == 3 else 6)] for e in lanes])
+        print(f"k_physics4 body {b} wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, np.median(st, axis=0))))
