@@ -175,6 +175,7 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   hp.cfg = *cfg; hp.model = *model;
   hp.h = cfg->dt / (float)cfg->substeps;
   hp.box_inv_I_k = cfg->has_box ? 6.f / (cfg->box_size * cfg->box_size) : 0.f;
+  hp.obs_div_magic = (unsigned)((0x100000000ull + (unsigned long long)cfg->num_obs - 1) / (unsigned long long)cfg->num_obs);
   {   // hand-level broadphase radius: chain of joint offsets from the palm to the capsule's joint + capsule extent + radius
     auto len3 = [](const float* v) { return std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); };
     double reach = 0.0;

@@ -59,6 +59,7 @@ struct DevParams {
   DexHandModel model;
   float h;           // sub-step
   float box_inv_I_k; // 6 / size^2 : inv inertia of a solid cube = box_inv_I_k / mass
+  unsigned obs_div_magic; // ceil(2^32 / num_obs): idx / num_obs == umulhi(idx, magic) for idx < 2^16 (obs_buf flush)
   float hand_reach;  // bound on |x - o5| over every point x of every hand capsule, for any joint configuration
                      // (o5 = origin of the palm joint frame): the hand-level broadphase of k_substep
   int obs_col_row[DEXSIM_OBS_ALL_DIM]; // obs_buf column -> obs_all row (flattened policy_observation_keys)
@@ -95,6 +96,9 @@ __device__ __forceinline__ void warm_params_done(int v) { asm volatile("" ::"v"(
 
 // ------------------------------------------------------------------------------------------------- math
 typedef float f2 __attribute__((ext_vector_type(2)));   // maps onto the gfx950 packed-FP32 VALU ops
+typedef float f4 __attribute__((ext_vector_type(4)));   // 16-byte global accesses
+// 16-byte store to global memory (address-space 1: no FLAT instruction even when the pointer came from memory)
+__device__ __forceinline__ void st4_global(float* p, f4 v) { *(__attribute__((address_space(1))) f4*)p = v; }
 
 struct V3 { float x, y, z; };
 struct Q4 { float x, y, z, w; };
