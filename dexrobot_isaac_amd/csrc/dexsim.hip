@@ -329,7 +329,7 @@ static int physics_step(dexsim_t h, int gate_on_reset, int tail, void* stream) {
     const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
     const dim3 grid(h->NS / 64), block(384);
     if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, tail, h->NS, h->N);
-    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, h->NS, h->N);
+    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, tail, h->NS, h->N);
     LAUNCH_CHECK();
     return DEXSIM_OK;
   }
@@ -369,6 +369,13 @@ int dexsim_step(dexsim_t h, const float* actions, void* stream) {
   NEED_BOUND(h);
   int rc = dexsim_process_actions(h, actions, 0, stream);   // also clears the per-step device flags
   if (rc) return rc;
+  if (h->cfg.substeps == 4) {
+    // physics + post-physics (+ phase 0 of the in-step reset) in one launch, then the device-gated extra physics step
+    // with phase 1 of the reset and the step statistics: a control step is 3 launches
+    rc = physics_step(h, 0, 2, stream);
+    if (rc) return rc;
+    return physics_step(h, 1, 1, stream);
+  }
   rc = dexsim_physics_step(h, 0, stream);
   if (rc) return rc;
   return dexsim_post_physics(h, 0, stream);
