@@ -324,12 +324,12 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 
 // tail != 0 (gated launch of the step path only): the launch also applies phase 1 of the in-step reset and finalises
 // the step statistics, so that a control step is k_actions, k_physics4, k_post, k_physics4<gated> and nothing else
-static int physics_step(dexsim_t h, int gate_on_reset, int tail, void* stream) {
+static int physics_step(dexsim_t h, int gate_on_reset, int tail, void* stream, const float* actions = nullptr) {
   if (h->cfg.substeps == 4) {   // the reference's setting: the whole sim.dt in one launch
     const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
     const dim3 grid(h->NS / 64), block(384);
-    if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, tail, h->NS, h->N);
-    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, tail, h->NS, h->N);
+    if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, tail, h->NS, h->N);
+    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, actions, tail, h->NS, h->N);
     LAUNCH_CHECK();
     return DEXSIM_OK;
   }
@@ -367,15 +367,16 @@ int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
 
 int dexsim_step(dexsim_t h, const float* actions, void* stream) {
   NEED_BOUND(h);
-  int rc = dexsim_process_actions(h, actions, 0, stream);   // also clears the per-step device flags
-  if (rc) return rc;
   if (h->cfg.substeps == 4) {
-    // physics + post-physics (+ phase 0 of the in-step reset) in one launch, then the device-gated extra physics step
-    // with phase 1 of the reset and the step statistics: a control step is 3 launches
-    rc = physics_step(h, 0, 2, stream);
+    // actions + physics + post-physics (+ phase 0 of the in-step reset) in one launch, then the device-gated extra
+    // physics step with phase 1 of the reset and the step statistics: a control step is 2 launches
+    if (!actions) return fail(DEXSIM_ERR_ARG, "Actions cannot be None");   // action_processor.py:296-297
+    int rc = physics_step(h, 0, 2, stream, actions);
     if (rc) return rc;
     return physics_step(h, 1, 1, stream);
   }
+  int rc = dexsim_process_actions(h, actions, 0, stream);   // also clears the per-step device flags
+  if (rc) return rc;
   rc = dexsim_physics_step(h, 0, stream);
   if (rc) return rc;
   return dexsim_post_physics(h, 0, stream);
