@@ -284,7 +284,7 @@ static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
 // one fused sub-step; `last` adds the contact-force accumulation and the publication
 static int launch_substep(dexsim_t h, int gate, int last, void* stream) {
   const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
-  const dim3 grid(h->NS / 64), block(384);
+  const dim3 grid(h->NS / 64), block(448);
   hipStream_t st = (hipStream_t)stream;
   if (gate && last) k_substep<true, true><<<grid, block, lds, st>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
   else if (gate) k_substep<true, false><<<grid, block, lds, st>>>(h->arena, h->api, h->d_params, h->api.counters, h->NS, h->N);
@@ -327,7 +327,7 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 static int physics_step(dexsim_t h, int gate_on_reset, int tail, void* stream, const float* actions = nullptr) {
   if (h->cfg.substeps == 4) {   // the reference's setting: the whole sim.dt in one launch
     const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
-    const dim3 grid(h->NS / 64), block(384);
+    const dim3 grid(h->NS / 64), block(448);
     if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, tail, h->NS, h->N);
     else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, actions, tail, h->NS, h->N);
     LAUNCH_CHECK();

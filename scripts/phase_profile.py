@@ -36,7 +36,7 @@ crow = core.field("crow").view(torch.int32).cpu().numpy()      # stamps of lane 
 names = ["base chain", "phase1 fingers|palm", "phase2 schur|narrow", "phase3 rows", "phase4 sweeps", "phase5 integrate", "publish"]
 lanes = np.arange(0, n, 64)
 print(f"N={n}: cycles since kernel start at each boundary, median over {len(lanes)} workgroups (s_memtime @100 MHz ticks x?)")
-for wv in range(6):
+for wv in range(7):
     st = np.array([[crow[wv * 8 + k, e] for k in range(7)] for e in lanes])
     med = np.median(st, axis=0)
     print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))
@@ -59,6 +59,6 @@ core.run_stage(_abi.STAGE["PHYSICS"])
 torch.cuda.synchronize()
 crow = core.field("crow").view(torch.int32).cpu().numpy()
 for b in range(4):
-    for wv in (0, 4, 5):
+    for wv in (0, 4, 5, 6):
         st = np.array([[crow[64 * (b + 1) + wv * 8 + k, e] for k in range(7 if b == 3 else 6)] for e in lanes])
         print(f"k_physics4 body {b} wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, np.median(st, axis=0))))
