@@ -130,16 +130,17 @@ def main():
         value = total_envs * args.steps / dt
         # live per-kernel timing with HIP events on the launch stream (one launch = one sub-step of all envs)
         kbar = float(core.stats[_abi.STAT["MEAN_CONTACTS"]].item())
-        t_phys = core.time_stage(_abi.STAGE["PHYSICS"], 50)    # production: one sim.dt = 4 fused sub-steps in one launch
+        core.step(actions[0])                                  # (DEXSIM_STAGE_STEP re-uses this launch's action pointer)
+        t_step = core.time_stage(_abi.STAGE["STEP"], 50)       # production launch: actions + 4 sub-steps + post-physics
         t_sub = core.time_stage(_abi.STAGE["SUBSTEP"], 50)     # a single sub-step (dynamics + solve + integrate + publish) as its own launch
         t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)     # the same sweeps as a stand-alone kernel
         t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)
         t_post = core.time_stage(_abi.STAGE["POST"], 20)
         t_pub = core.time_stage(_abi.STAGE["PUBLISH"], 20)
         peak = 8000.0
+        step_bytes = 2560.0                            # algorithmic bytes of a whole env-step
         # algorithmic HBM bytes per env per launch
         b_sub = (632.0 + 204.0) * N                    # q, qd, targets, box in; q, qd, box out; cforce (last sub-step)
-        b_phys = (4 * 632.0 + 204.0) * N               # per-invocation figure x the 4 solver invocations of one launch
         b_solve = (256.0 + 60.0 * kbar) * N
         b_dyn = (500.0 + 36.0 * kbar) * N
         pmc = {}
@@ -158,7 +159,6 @@ def main():
             return {"bound": "hbm", "achieved": a, "peak": peak, "unit": "GB/s", "frac": a / peak, "traffic": tr,
                     "kernel": kernel, "avg_us": us, "algorithmic_bytes": bytes_, "mean_contacts": kbar}
 
-        step_bytes = 2560.0                            # SURVEY.md section 8d whole env-step
         out = {
             "metric": "env-steps/sec BlindGrasping num_envs=4096 per MI355X (random actions)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,13 +169,15 @@ def main():
                        "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
                        "domain_randomisation": bool(args.dr)},
             "resets_per_step": resets / args.steps,
-            "roofline": roof("k_physics4", b_phys, t_phys),
+            # dominant kernel = the one launch that carries a whole control step (k_physics4<false> with the action and
+            # post-physics blocks); algorithmic bytes = SURVEY 8d's whole-env-step figure
+            "roofline": roof("k_physics4", step_bytes * N, t_step),
             "roofline_substep": roof("k_substep", b_sub, t_sub),
             "roofline_contact_solve": roof("k_solve", b_solve, t_solve),
             "roofline_dynamics": roof("k_dynamics", b_dyn, t_dyn),
             "roofline_whole_step": {"bound": "hbm", "achieved": step_bytes * value / world / 1e9, "peak": peak,
                                     "unit": "GB/s", "frac": step_bytes * value / world / 1e9 / peak, "traffic": None},
-            "kernel_us": {"k_physics4": t_phys, "k_substep": t_sub, "k_dynamics": t_dyn, "k_solve": t_solve, "k_post": t_post, "k_publish": t_pub},
+            "kernel_us": {"k_physics4_step": t_step, "k_substep": t_sub, "k_dynamics": t_dyn, "k_solve": t_solve, "k_post": t_post, "k_publish": t_pub},
         }
         if world == 1 and not args.no_stagger:
             # Secondary figure, NOT `value`: the timed region above starts from a fresh env, like the reference's own run,

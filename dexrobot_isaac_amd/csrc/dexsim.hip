@@ -41,6 +41,7 @@ struct DexSim {
   ApiPtrs api;
   bool bound;
   hipEvent_t ev0, ev1;
+  const float* last_actions;   // device pointer of the last dexsim_step (DEXSIM_STAGE_STEP re-launches the same kernel)
 };
 
 static int padded(int n) { return (n + 63) / 64 * 64; }
@@ -371,6 +372,7 @@ int dexsim_step(dexsim_t h, const float* actions, void* stream) {
     // actions + physics + post-physics (+ phase 0 of the in-step reset) in one launch, then the device-gated extra
     // physics step with phase 1 of the reset and the step statistics: a control step is 2 launches
     if (!actions) return fail(DEXSIM_ERR_ARG, "Actions cannot be None");   // action_processor.py:296-297
+    h->last_actions = actions;
     int rc = physics_step(h, 0, 2, stream, actions);
     if (rc) return rc;
     return physics_step(h, 1, 1, stream);
@@ -432,6 +434,9 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
     case DEXSIM_STAGE_PUBLISH: return launch_publish(h, 0, 0, stream);
     case DEXSIM_STAGE_SUBSTEP: return launch_substep(h, 0, 1, stream);
     case DEXSIM_STAGE_PHYSICS: return physics_step(h, 0, 0, stream);
+    case DEXSIM_STAGE_STEP:   // the production launch of dexsim_step: actions + 4 sub-steps + post-physics, same arguments
+      if (h->cfg.substeps != 4 || !h->last_actions) return fail(DEXSIM_ERR_ARG, "DEXSIM_STAGE_STEP needs substeps == 4 and a previous dexsim_step");
+      return physics_step(h, 0, 2, stream, h->last_actions);
     case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_RESET:

@@ -336,7 +336,9 @@ int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, voi
 #define DEXSIM_STAGE_RESET    4  /* masked reset of envs whose reset_buf is set                     */
 #define DEXSIM_STAGE_FINALIZE 5  /* statistics                                                      */
 #define DEXSIM_STAGE_SUBSTEP  6  /* one sub-step (DYNAMICS + SOLVE + integration + publication) as its own launch */
-#define DEXSIM_STAGE_PHYSICS  7  /* production physics step: all `substeps` of a sim.dt (one launch when substeps == 4) */
+#define DEXSIM_STAGE_PHYSICS  7  /* physics step alone: all `substeps` of a sim.dt (one launch when substeps == 4)      */
+#define DEXSIM_STAGE_STEP     8  /* the launch dexsim_step issues: actions + 4 sub-steps + post-physics (re-uses the    */
+                                 /* action pointer of the last dexsim_step; advances the simulation)                    */
 int dexsim_run_stage(dexsim_t h, int stage, void* stream);
 
 /* Time `launches` back-to-back launches of one stage with hipEvents on `stream`; returns the mean
