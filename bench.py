@@ -130,8 +130,12 @@ def main():
         value = total_envs * args.steps / dt
         # live per-kernel timing with HIP events on the launch stream (one launch = one sub-step of all envs)
         kbar = float(core.stats[_abi.STAT["MEAN_CONTACTS"]].item())
-        core.step(actions[0])                                  # (DEXSIM_STAGE_STEP re-uses this launch's action pointer)
-        t_step = core.time_stage(_abi.STAGE["STEP"], 50)       # production launch: actions + 4 sub-steps + post-physics
+        # the production launch (k_physics4: actions + 4 sub-steps + post-physics), timed in situ: hipEvent pairs on the
+        # launch stream around that kernel during 64 ordinary, un-synchronised control steps
+        core.step_timing(True)
+        for i in range(64):                                    # (no rollout gather here: this block runs on rank 0 only)
+            core.step(actions[i % n_act])
+        t_step, _ = core.step_timing(False)
         t_sub = core.time_stage(_abi.STAGE["SUBSTEP"], 50)     # a single sub-step (dynamics + solve + integrate + publish) as its own launch
         t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)     # the same sweeps as a stand-alone kernel
         t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)

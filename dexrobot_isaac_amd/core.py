@@ -172,6 +172,12 @@ class DexSimCore:
     def run_stage(self, stage):
         check(self.lib.dexsim_run_stage(self.h, int(stage), self._stream()), "run_stage")
 
+    def step_timing(self, enable):
+        """Start (True) / stop (False) the in-situ hipEvent timing of dexsim_step's main launch; stop returns (mean_us, n)."""
+        us, n = C.c_float(0.0), C.c_int(0)
+        check(self.lib.dexsim_step_timing(self.h, 1 if enable else 0, C.byref(us), C.byref(n)), "step_timing")
+        return float(us.value), int(n.value)
+
     def time_stage(self, stage, launches):
         us = C.c_float(0)
         check(self.lib.dexsim_time_stage(self.h, int(stage), int(launches), self._stream(), C.byref(us)), "time_stage")

@@ -42,6 +42,8 @@ struct DexSim {
   bool bound;
   hipEvent_t ev0, ev1;
   const float* last_actions;   // device pointer of the last dexsim_step (DEXSIM_STAGE_STEP re-launches the same kernel)
+  hipEvent_t tev[128];         // dexsim_step_timing: ring of 64 (start, stop) pairs
+  int timing;                  // 0 = off, else 1 + number of steps recorded since it was switched on
 };
 
 static int padded(int n) { return (n + 63) / 64 * 64; }
@@ -226,6 +228,7 @@ int dexsim_destroy(dexsim_t h) {
   (void)hipFree(h->d_params);
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
+  if (h->tev[0]) for (int i = 0; i < 128; i++) (void)hipEventDestroy(h->tev[i]);
   delete h;
   return DEXSIM_OK;
 }
@@ -373,8 +376,11 @@ int dexsim_step(dexsim_t h, const float* actions, void* stream) {
     // physics step with phase 1 of the reset and the step statistics: a control step is 2 launches
     if (!actions) return fail(DEXSIM_ERR_ARG, "Actions cannot be None");   // action_processor.py:296-297
     h->last_actions = actions;
+    const int slot = h->timing ? ((h->timing - 1) & 63) : -1;
+    if (slot >= 0) HIP_TRY(hipEventRecord(h->tev[2 * slot], (hipStream_t)stream));
     int rc = physics_step(h, 0, 2, stream, actions);
     if (rc) return rc;
+    if (slot >= 0) { HIP_TRY(hipEventRecord(h->tev[2 * slot + 1], (hipStream_t)stream)); h->timing++; }
     return physics_step(h, 1, 1, stream);
   }
   int rc = dexsim_process_actions(h, actions, 0, stream);   // also clears the per-step device flags
@@ -475,6 +481,28 @@ int dexsim_time_stage(dexsim_t h, int stage, int launches, void* stream, float* 
     total += ms;
   }
   *mean_us = (float)(total * 1000.0 / launches);
+  return DEXSIM_OK;
+}
+
+int dexsim_step_timing(dexsim_t h, int enable, float* mean_us, int* n) {
+  NEED_BOUND(h);
+  if (enable) {
+    if (!h->tev[0]) for (int i = 0; i < 128; i++) HIP_TRY(hipEventCreate(&h->tev[i]));
+    h->timing = 1;
+    return DEXSIM_OK;
+  }
+  const int rec = h->timing ? h->timing - 1 : 0;
+  h->timing = 0;
+  const int cnt = rec < 64 ? rec : 64;
+  double tot = 0.0;
+  for (int i = 0; i < cnt; i++) {
+    HIP_TRY(hipEventSynchronize(h->tev[2 * i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->tev[2 * i], h->tev[2 * i + 1]));
+    tot += ms;
+  }
+  if (mean_us) *mean_us = cnt ? (float)(tot * 1000.0 / cnt) : 0.f;
+  if (n) *n = cnt;
   return DEXSIM_OK;
 }
 

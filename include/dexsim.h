@@ -345,6 +345,12 @@ int dexsim_run_stage(dexsim_t h, int stage, void* stream);
  * duration in microseconds (used by bench.py for the roofline line). */
 int dexsim_time_stage(dexsim_t h, int stage, int launches, void* stream, float* mean_us);
 
+/* In-situ timing of the main launch of dexsim_step (k_physics4 with the action and post-physics blocks when
+ * substeps == 4): enable != 0 starts recording a hipEvent pair around that launch on every following dexsim_step
+ * (ring of 64, no host synchronisation, so the launches stay back to back as in production); enable == 0 stops,
+ * synchronises and returns the mean duration in microseconds over the *n recorded steps.  bench.py's roofline line. */
+int dexsim_step_timing(dexsim_t h, int enable, float* mean_us, int* n);
+
 const char* dexsim_error_string(int code);
 const char* dexsim_last_error(void);
 
