@@ -112,8 +112,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()                             # HIP events on the launch stream, around the whole timed region
     run(args.steps)
+    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -130,12 +133,12 @@ def main():
         value = total_envs * args.steps / dt
         # live per-kernel timing with HIP events on the launch stream (one launch = one sub-step of all envs)
         kbar = float(core.stats[_abi.STAT["MEAN_CONTACTS"]].item())
-        # the production launch (k_physics4: actions + 4 sub-steps + post-physics), timed in situ: hipEvent pairs on the
-        # launch stream around that kernel during 64 ordinary, un-synchronised control steps
-        core.step_timing(True)
-        for i in range(64):                                    # (no rollout gather here: this block runs on rank 0 only)
-            core.step(actions[i % n_act])
-        t_step, _ = core.step_timing(False)
+        # The production launch (k_physics4<false>: actions + 4 sub-steps + post-physics) is issued once per control step,
+        # so its mean duration over the timed region = GPU time between the two HIP events / steps, minus nothing: the
+        # figure therefore also contains the device-gated no-op launch (~3 us) and the dispatch gaps -- an upper bound.
+        # A hipEvent pair around each single launch is NOT used: the event's release/acquire fences make the kernel
+        # start from a cold L2 (rocprofv3 shows 125 us instead of 94 us for such launches, profiles/round1_d_*).
+        t_step = ev0.elapsed_time(ev1) * 1e3 / args.steps
         t_sub = core.time_stage(_abi.STAGE["SUBSTEP"], 50)     # a single sub-step (dynamics + solve + integrate + publish) as its own launch
         t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)     # the same sweeps as a stand-alone kernel
         t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)
