@@ -95,6 +95,41 @@ def test_teacher_forced_substep_matches_oracle(task, fused):
     np.testing.assert_allclose(hb.get("hand_vel"), o.get("hand_vel"), atol=2e-5)
 
 
+@pytest.mark.parametrize("z_range", [(-0.1, 0.2), (-0.36, -0.30), (-0.43, -0.38)], ids=["hand_clear", "sphere_fails_capsules_clear", "touching"])
+def test_broadphase_regimes_match_oracle(z_range):
+    """The sub-step kernel has three regimes per workgroup -- hand bounding sphere clear (early box solve), sphere not
+    clear but every capsule passes its bounds, and the general contact path -- and mixes of them across workgroups.
+    Each must give the oracle's contact lists and state after a full physics step (4 sub-steps in one launch)."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 320                                          # 5 workgroups
+    sc, model = _mk("BlindGrasping", n)
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms), HipBackend(sc, ms)
+    rng = np.random.default_rng(17)
+    st = _random_state(rng, model, n)
+    st["q"][2] = rng.uniform(z_range[0], z_range[1], n)
+    st["q"][2, :64] = rng.uniform(-0.1, 0.2, 64)    # first workgroup always far from the box: regimes mix across workgroups
+    st["q"] = np.clip(st["q"], model.lo[:, None] + 1e-3, model.hi[:, None] - 1e-3)
+    st["targets"] = st["q"] + rng.normal(0, 0.02, (26, n))
+    st["qd"] *= 0.2
+    for k, v in st.items():
+        o.set(k, v)
+        hb.set(k, v)
+    o.physics_step()
+    hb.physics_step()
+    nc_o, nc_h = o.get("ncontact")[0], hb.get("ncontact")[0]
+    assert (nc_o == nc_h).all(), f"contact count differs in {(nc_o != nc_h).sum()} envs"
+    if z_range[0] > -0.2:
+        assert nc_o.max() <= 4                       # box/ground contacts only
+    if z_range[1] < -0.37:
+        assert nc_o.max() >= 5                       # fingers really touch box or ground
+    np.testing.assert_allclose(hb.get("q"), o.get("q"), atol=5e-4)
+    np.testing.assert_allclose(hb.get("box_pos"), o.get("box_pos"), atol=5e-4)
+    np.testing.assert_allclose(hb.get("box_lin"), o.get("box_lin"), atol=2e-2, rtol=5e-3)
+    np.testing.assert_allclose(hb.get("site_pose"), o.get("site_pose"), atol=5e-4)
+
+
 def test_contact_manifold_matches_oracle():
     """Narrowphase only: identical contact lists (type, capsule, order) and geometry within 1e-6."""
     from oracle.oracle import Oracle
