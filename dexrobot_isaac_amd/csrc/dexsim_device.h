@@ -226,6 +226,25 @@ DI void tangent_basis(V3 n, V3& t1, V3& t2) {
   t2 = cross(n, t1);
 }
 
+// sin and cos of a joint half-angle.  libm's sincosf costs ~145 instructions on gfx950 (its Payne-Hanek large-argument
+// reduction is inlined branch-free) and sits 7 times on every wave's critical path per sub-step; joint angles are
+// bounded, so one Cody-Waite step to [-pi/4, pi/4] and the classic single-precision minimax kernels (Cephes sinf /
+// cosf coefficients, < 1 ulp on the reduced range) do the same job in ~25.  Valid to full accuracy for |h| < ~100.
+__device__ __forceinline__ void sincos_joint(float h, float* sn, float* cs) {
+  const float kf = rintf(h * 0.6366197723675814f);            // nearest multiple of pi/2
+  float r = fmaf(kf, -1.5707963705062866f, h);                 // pi/2 split in two floats (Cody-Waite)
+  r = fmaf(kf, 4.371139000186241e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                        fmaf(-0.5f, z, 1.0f));
+  const int k = (int)kf;
+  const bool swap = (k & 1) != 0;
+  const float s0 = swap ? pc : ps, c0 = swap ? ps : pc;
+  *sn = (k & 2) ? -s0 : s0;
+  *cs = ((k + 1) & 2) ? -c0 : c0;
+}
+
 // Philox4x32-10 (device-side reset / domain-randomisation stream)
 DI void philox4x32(uint32_t out[4], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   uint32_t c[4] = {c0, c1, c2, c3};
