@@ -179,6 +179,32 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   hp.h = cfg->dt / (float)cfg->substeps;
   hp.box_inv_I_k = cfg->has_box ? 6.f / (cfg->box_size * cfg->box_size) : 0.f;
   hp.obs_div_magic = (unsigned)((0x100000000ull + (unsigned long long)cfg->num_obs - 1) / (unsigned long long)cfg->num_obs);
+  {   // base-chain constants (double precision on the host): see base_chain()
+    struct Qd { double x, y, z, w; };
+    auto qmul = [](Qd a, Qd b) {
+      return Qd{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+                a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+    };
+    auto qrot = [&](Qd q, const double* v, double* out) {   // R(q) v
+      const Qd p{v[0], v[1], v[2], 0.0}, c{-q.x, -q.y, -q.z, q.w};
+      const Qd r = qmul(qmul(q, p), c);
+      out[0] = r.x; out[1] = r.y; out[2] = r.z;
+    };
+    Qd qc{model->spawn_quat[0], model->spawn_quat[1], model->spawn_quat[2], model->spawn_quat[3]};
+    double oc[3] = {model->spawn_pos[0], model->spawn_pos[1], model->spawn_pos[2]};
+    for (int j = 0; j < 4; j++) {
+      const double poff[3] = {model->jpoff[j][0], model->jpoff[j][1], model->jpoff[j][2]};
+      const double ax[3] = {model->jaxis[j][0], model->jaxis[j][1], model->jaxis[j][2]};
+      double d[3], aw[3];
+      qrot(qc, poff, d);
+      for (int i = 0; i < 3; i++) oc[i] += d[i];
+      const Qd qz = qmul(qc, Qd{model->jqoff[j][0], model->jqoff[j][1], model->jqoff[j][2], model->jqoff[j][3]});
+      qrot(qz, ax, aw);
+      for (int i = 0; i < 3; i++) { hp.base_A[j][i] = (float)aw[i]; hp.base_Oc[j][i] = (float)oc[i]; }
+      qc = qz;   // prismatic joints keep the orientation; for joint 3 this is the frame at q3 = 0
+    }
+    hp.base_Q3z[0] = (float)qc.x; hp.base_Q3z[1] = (float)qc.y; hp.base_Q3z[2] = (float)qc.z; hp.base_Q3z[3] = (float)qc.w;
+  }
   {   // hand-level broadphase radius: chain of joint offsets from the palm to the capsule's joint + capsule extent + radius
     auto len3 = [](const float* v) { return std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); };
     double reach = 0.0;

@@ -59,6 +59,9 @@ struct DevParams {
   DexHandModel model;
   float h;           // sub-step
   float box_inv_I_k; // 6 / size^2 : inv inertia of a solid cube = box_inv_I_k / mass
+  // closed form of the configuration-independent part of the base chain (joints 0-2 prismatic, joint 3 the first
+  // revolute): world axes A_j, the constant part Oc_j of the origin of joint frame j, orientation of frame 3 at q3 = 0
+  float base_A[4][3], base_Oc[4][3], base_Q3z[4];
   unsigned obs_div_magic; // ceil(2^32 / num_obs): idx / num_obs == umulhi(idx, magic) for idx < 2^16 (obs_buf flush)
   float hand_reach;  // bound on |x - o5| over every point x of every hand capsule, for any joint configuration
                      // (o5 = origin of the palm joint frame): the hand-level broadphase of k_substep
