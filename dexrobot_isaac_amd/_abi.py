@@ -24,6 +24,7 @@ STAT = dict(SUCC_MEAN=0, FAIL_MEAN=4, SUCCESS_RATE=12, FAILURE_RATE=13, TIMEOUT_
 
 TASK_BASE, TASK_BLIND_GRASPING = 0, 1
 MODE_POSITION, MODE_POSITION_DELTA = 0, 1
+CNT_ANY_RESET, CNT_CONTACTS = 0, 12   # dexsim_device.h: device-side control flags inside the counters block
 STAGE = dict(DYNAMICS=0, SOLVE=1, PUBLISH=2, POST=3, RESET=4, FINALIZE=5, SUBSTEP=6, PHYSICS=7, STEP=8)
 
 SUCCESS_CRITERIA = ["grasp_lift_success"]

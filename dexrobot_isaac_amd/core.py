@@ -141,6 +141,12 @@ class DexSimCore:
     def process_actions(self, actions, zero_targets=False):
         check(self.lib.dexsim_process_actions(self.h, self._actions_ptr(actions), int(zero_targets), self._stream()), "process_actions")
 
+    def begin_step(self):
+        """Clear the per-step device flags (what k_actions does at the start of a control step); used when the action
+        stage ran on the host."""
+        self.counters[_abi.CNT_ANY_RESET] = 0
+        self.counters[_abi.CNT_CONTACTS] = 0
+
     def physics_step(self, gate_on_reset=False):
         check(self.lib.dexsim_physics_step(self.h, int(gate_on_reset), self._stream()), "physics_step")
 

@@ -68,6 +68,78 @@ class _ActionProcessorView:
         self.action_scaling = _ActionScalingView()
         self._pre_action_rule = None
         self._action_rule = None
+        # post-action filters (rules.py:113-135): registry + enabled list.  The two built-ins run inside the action
+        # kernel; as soon as a custom filter is enabled or a custom coupling rule is set, the whole action stage runs
+        # on the host in torch (this file) and only its results are handed to the device (slow path, see env.step).
+        self._post_action_filter_registry = {
+            "velocity_clamp": lambda prev, rule, tgt: prev + torch.clamp(tgt - prev, -self.max_deltas, self.max_deltas),
+            "position_clamp": lambda prev, rule, tgt: torch.clamp(tgt, self.active_lower_limits, self.active_upper_limits),
+        }
+        self._enabled_post_action_filters = ["velocity_clamp", "position_clamp"]   # dexhand_base.py:478-481
+        self._coupling_rule = None
+        # coupling table as index / scale tensors for the host path (constants.py:71-88)
+        name_to_dof = {n: i for i, n in enumerate(env.model.dof_names)}
+        ctrl, dof, scale = [], [], []
+        for f, lst in FINGER_COUPLING_MAP.items():
+            for jn, sc in lst:
+                ctrl.append(6 + f); dof.append(name_to_dof[jn]); scale.append(sc)
+        self._cpl_ctrl = torch.tensor(ctrl, device=dev)
+        self._cpl_dof = torch.tensor(dof, device=dev)
+        self._cpl_scale = torch.tensor(scale, device=dev, dtype=torch.float32)
+
+    def _host_path(self):
+        """True when the action stage cannot run in the HIP kernel: custom filter enabled or custom coupling rule."""
+        return self._coupling_rule is not None or self._enabled_post_action_filters != ["velocity_clamp", "position_clamp"]
+
+    def _default_action_rule(self, prev, rule_targets, actions):
+        """default_rules.py:33-112 (position / position_delta), torch restatement for the host path."""
+        raw = rule_targets.clone()
+        na = actions.shape[1]
+        fs = 6 if self.policy_controls_hand_base else 0
+        a = torch.zeros(actions.shape[0], 18, device=actions.device, dtype=actions.dtype)
+        if self.policy_controls_hand_base:
+            a[:, :6] = actions[:, :6]
+        if self.policy_controls_fingers:
+            a[:, 6:] = actions[:, fs:fs + 12] if na >= fs + 12 else 0.0
+        m = self.active_target_mask
+        if self.action_control_mode == "position_delta":
+            raw[:, m] = prev[:, m] + a[:, m] * self.max_deltas[m]
+            raw = torch.clamp(raw, self.active_lower_limits, self.active_upper_limits)
+        else:
+            lo, hi = self.active_lower_limits, self.active_upper_limits
+            raw[:, m] = ((a + 1.0) * 0.5 * (hi - lo) + lo)[:, m]
+        return raw
+
+    def _host_process_actions(self, actions):
+        """ActionProcessor.process_actions on the host (action_processor.py:284-352): rule -> enabled filters in order
+        -> coupling; writes the results into the device state the kernels read."""
+        core = self._env._core
+        prev, rule_t = self.active_prev_targets.clone(), self.active_rule_targets.clone()
+        if self._action_rule is not None:
+            config = {"control_mode": self.action_control_mode, "policy_controls_base": self.policy_controls_hand_base,
+                      "policy_controls_fingers": self.policy_controls_fingers}
+            raw = self._action_rule(prev, rule_t, actions, config)
+        else:
+            raw = self._default_action_rule(prev, rule_t, actions)
+        nxt = raw
+        for name in self._enabled_post_action_filters:
+            fn = self._post_action_filter_registry.get(name)
+            if fn is not None:                                   # rules.py:122-133: unknown names are skipped
+                nxt = fn(prev, rule_t, nxt)
+        if self._coupling_rule is not None:
+            full = self._coupling_rule(nxt)
+        else:
+            full = torch.zeros(nxt.shape[0], 26, device=nxt.device, dtype=nxt.dtype)
+            full[:, :6] = nxt[:, :6]
+            full[:, self._cpl_dof] = nxt[:, self._cpl_ctrl] * self._cpl_scale
+        core.field("active_prev_targets").copy_(nxt.t())
+        core.field("targets").copy_(full.t())
+        core.full_dof_targets.copy_(full)
+        a18 = torch.zeros(actions.shape[0], 18, device=actions.device, dtype=actions.dtype)
+        a18[:, :actions.shape[1]] = actions
+        core.field("actions").copy_(a18.t())
+        core.field("prev_actions").copy_(a18.t())
+        core.begin_step()
 
     @property
     def active_prev_targets(self):
@@ -97,12 +169,14 @@ class _ActionProcessorView:
             self._env._core.set_raw_targets(None)
 
     def register_post_action_filter(self, name, filter_fn):
-        raise NotImplementedError("custom post-action filters are not wired yet (SURVEY.md §8f rank 4); the built-in "
-                                  "velocity_clamp and position_clamp run inside the action kernel")
+        """filter_fn(active_prev_targets, active_rule_targets, active_targets) -> filtered (rules.py:113-135).  Like in the
+        reference, registering does not enable: the name must also be in `_enabled_post_action_filters`
+        (dexhand_base.py:255-261 extends that list with the task's `post_action_filters`)."""
+        self._post_action_filter_registry[name] = filter_fn
 
     def set_coupling_rule(self, rule):
-        raise NotImplementedError("custom coupling rules are not wired yet; the reference coupling table "
-                                  "(constants.py:71-88) is compiled into the action kernel")
+        """rule(active_targets (N,18)) -> full_dof_targets (N,26) (action_processor.py:698-705); None restores the table."""
+        self._coupling_rule = rule
 
     def unscale_actions(self, actions):
         """actions in [-1, 1] -> physical units (action_processor.py:721-755)."""
@@ -384,6 +458,13 @@ class DexHandEnv:
             raise RuntimeError("Actions cannot be None")
         self.actions = actions.clone()                           # dexhand_base.py:851
         ap = self.action_processor
+        if ap._host_path():
+            # custom post-action filter / coupling rule: action stage in torch on the host, then the staged device path
+            ap._host_process_actions(self.actions)
+            self._core.physics_step(False)
+            self._core.post_physics(False)
+            self._apply_pre_action_rule()
+            return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
         if ap._action_rule is not None:
             config = {"control_mode": ap.action_control_mode, "policy_controls_base": ap.policy_controls_hand_base,
                       "policy_controls_fingers": ap.policy_controls_fingers}

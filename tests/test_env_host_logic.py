@@ -116,7 +116,11 @@ def test_reset_idx_and_hooks():
     env.step(torch.zeros(6, 18))
     assert calls and calls[0] == ["env", "obs_dict"]
     assert torch.allclose(env.get_observations_dict()["active_rule_targets"][:, 0], torch.full((6,), 0.05))
-    with pytest.raises(NotImplementedError):
-        env.action_processor.register_post_action_filter("x", lambda a, b, c: c)
+    # registering a filter does not enable it (rules.py:113-135): the fused device path stays selected
+    env.action_processor.register_post_action_filter("x", lambda a, b, c: c)
+    assert not env.action_processor._host_path()
+    env.action_processor._enabled_post_action_filters = ["velocity_clamp", "position_clamp", "x"]
+    assert env.action_processor._host_path()
+    env.action_processor._enabled_post_action_filters = ["velocity_clamp", "position_clamp"]
     with pytest.raises(RuntimeError, match="None"):
         env.step(None)

@@ -347,3 +347,52 @@ def test_action_sweep_like_reference_harness():
     assert float((env.dof_pos[0] - q0[0]).abs().max()) < 0.1      # "Hand returned close to initial position"
     assert torch.isfinite(env.obs_buf).all()
     env.close()
+
+
+def test_custom_post_action_filter_and_coupling_rule_host_path():
+    """register_post_action_filter / set_coupling_rule (action_processor.py:698-720): with a custom filter enabled or a
+    custom coupling rule set, the action stage runs on the host (torch) and the staged device path does the rest.  An
+    identity filter plus a coupling rule that restates the table must reproduce the fused single-launch step; a filter
+    that halves the commanded change must show up in the targets."""
+    import torch
+    from dexrobot_isaac_amd import make_env
+    from dexrobot_isaac_amd.config import default_cfg
+
+    def mk():
+        cfg = default_cfg("BlindGrasping")
+        cfg["env"]["numEnvs"] = 128
+        return make_env("BlindGrasping", 128, "cuda:0", "cuda:0", 0, cfg=cfg)
+
+    ref, env = mk(), mk()
+    ap = env.action_processor
+    ap.register_post_action_filter("identity", lambda prev, rule, tgt: tgt)
+    ap._enabled_post_action_filters = ap._enabled_post_action_filters + ["identity"]   # dexhand_base.py:255-261
+    tbl_ctrl, tbl_dof, tbl_scale = ap._cpl_ctrl.clone(), ap._cpl_dof.clone(), ap._cpl_scale.clone()
+
+    def coupling(active):
+        full = torch.zeros(active.shape[0], 26, device=active.device)
+        full[:, :6] = active[:, :6]
+        full[:, tbl_dof] = active[:, tbl_ctrl] * tbl_scale
+        return full
+    ap.set_coupling_rule(coupling)
+    assert ap._host_path() and not ref.action_processor._host_path()
+    ref.reset(); env.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    for t in range(12):
+        a = 2 * torch.rand(128, 18, device="cuda:0", generator=g) - 1
+        o1, r1, d1, _ = ref.step(a)
+        o2, r2, d2, _ = env.step(a)
+        torch.testing.assert_close(env.full_dof_targets, ref.full_dof_targets, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(o2, o1, atol=2e-4, rtol=1e-4)
+        assert bool((d1 == d2).all())
+    # a filter that halves the step towards the raw target
+    ap.register_post_action_filter("half", lambda prev, rule, tgt: prev + 0.5 * (tgt - prev))
+    ap._enabled_post_action_filters = ["velocity_clamp", "position_clamp", "half"]
+    ap.set_coupling_rule(None)
+    prev = ap.active_prev_targets.clone()
+    prev_ref = ref.action_processor.active_prev_targets.clone()
+    a = torch.ones(128, 18, device="cuda:0")
+    env.step(a); ref.step(a)
+    d_env = (ap.active_prev_targets - prev)[:, :6]
+    d_ref = (ref.action_processor.active_prev_targets - prev_ref)[:, :6]
+    torch.testing.assert_close(d_env, 0.5 * d_ref, atol=1e-6, rtol=1e-5)
