@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--horizon", type=int, default=16, help="rollout length between RCCL gathers (gpus > 1)")
     ap.add_argument("--dr", action="store_true", help="BASELINE config #5: per-env box mass/friction randomisation")
+    ap.add_argument("--task", default="BlindGrasping", choices=["BlindGrasping", "BaseTask"],
+                    help="BaseTask + --control-mode position + --num-envs 1024 = BASELINE configs[1] (articulated FD only, no object)")
+    ap.add_argument("--control-mode", default=None, choices=["position", "position_delta"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", action="store_true", help="skip the secondary staggered-episode measurement")
     args = ap.parse_args()
@@ -75,8 +78,10 @@ def main():
     device = torch.device("cuda", local_rank)
 
     def factory(n):
-        cfg = default_cfg("BlindGrasping")
+        cfg = default_cfg(args.task)
         cfg["env"]["numEnvs"] = n
+        if args.control_mode:
+            cfg["task"]["controlMode"] = args.control_mode
         dr = {"mass": (0.05, 0.2), "friction": (0.5, 1.5), "seed": 4242 + rank} if args.dr else None
         return build_sim_config(cfg, dr=dr)
 
@@ -167,11 +172,13 @@ def main():
                     "kernel": kernel, "avg_us": us, "algorithmic_bytes": bytes_, "mean_contacts": kbar}
 
         out = {
-            "metric": "env-steps/sec BlindGrasping num_envs=4096 per MI355X (random actions)",
+            "metric": f"env-steps/sec {args.task} num_envs={N} per MI355X (random actions)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BlindGrasping num_envs=4096/GPU (BASELINE configs[2]; configs[3] when n_gpus>1)",
+            "config": {"workload": (f"{args.task} num_envs={N}/GPU" + (" (BASELINE configs[2]; configs[3] when n_gpus>1)"
+                                    if args.task == "BlindGrasping" and N == 4096 and not args.dr else "")),
+                       "control_mode": args.control_mode or "task default",
                        "num_envs_per_gpu": N, "sim_dt": 0.01, "substeps": 4, "pgs_iterations": 16,
                        "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
                        "domain_randomisation": bool(args.dr)},
