@@ -396,3 +396,26 @@ def test_custom_post_action_filter_and_coupling_rule_host_path():
     d_env = (ap.active_prev_targets - prev)[:, :6]
     d_ref = (ref.action_processor.active_prev_targets - prev_ref)[:, :6]
     torch.testing.assert_close(d_env, 0.5 * d_ref, atol=1e-6, rtol=1e-5)
+
+
+def test_step_timing_and_step_stage_entry_points():
+    """dexsim_step_timing (in-situ hipEvent pairs around the step launch) and DEXSIM_STAGE_STEP (re-launch of the
+    production kernel with the last action pointer) behave as declared in include/dexsim.h."""
+    import torch
+    from dexrobot_isaac_amd import _abi
+    from dexrobot_isaac_amd.core import DexSimCore
+    sc, model = _mk("BlindGrasping", 256)
+    core = DexSimCore(sc, model.to_struct(), "cuda:0")
+    core.reset()
+    a = 2 * torch.rand(256, 18, device="cuda:0") - 1
+    core.step_timing(True)
+    for _ in range(5):
+        core.step(a)
+    us, n = core.step_timing(False)
+    assert n == 5 and 10.0 < us < 5000.0
+    q0 = core.field("q").clone()
+    core.run_stage(_abi.STAGE["STEP"])               # advances the simulation by one control step (minus the gated launch)
+    torch.cuda.synchronize()
+    assert torch.isfinite(core.obs_buf).all() and not torch.equal(core.field("q"), q0)
+    t = core.time_stage(_abi.STAGE["PHYSICS"], 3)
+    assert t > 0
