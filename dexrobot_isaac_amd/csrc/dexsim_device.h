@@ -71,19 +71,6 @@ struct DevParams {
                      // through the scalar cache instead of pinning 114 SGPRs of by-value kernel arguments
 };
 
-// A kernel boundary invalidates the scalar cache and this XCD's L2, so the first scalar load of every 64-B line of
-// DevParams goes all the way to the Infinity Cache / HBM (~2 us) and the kernels touch those lines a few at a time
-// along their critical path.  One vector load per line at kernel entry (all lines in flight at once, overlapped
-// with the first arena loads) pulls the whole block into L2; the later scalar misses then cost an L2 hit.
-// The returned value must be consumed at kernel exit (warm_params_done) so the loads are not dropped.
-__device__ __forceinline__ int warm_params(const DevParams* P, int tid, int nthreads) {
-  int acc = 0;
-  const char* base = (const char*)P;
-  for (int off = tid * 64; off < (int)sizeof(DevParams); off += nthreads * 64) acc ^= *(const volatile int*)(base + off);
-  return acc;
-}
-__device__ __forceinline__ void warm_params_done(int v) { asm volatile("" ::"v"(v)); }
-
 // counters block (ints): reduction scratch + device-side control flags
 #define CNT_ANY_RESET 0   /* set by the post kernel when some env must reset this step          */
 #define CNT_SUCC 1        /* [NUM_SUCC] */
