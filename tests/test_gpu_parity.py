@@ -419,3 +419,27 @@ def test_step_timing_and_step_stage_entry_points():
     assert torch.isfinite(core.obs_buf).all() and not torch.equal(core.field("q"), q0)
     t = core.time_stage(_abi.STAGE["PHYSICS"], 3)
     assert t > 0
+
+
+@pytest.mark.parametrize("near_box", [False, True], ids=["hand_clear", "contacts"])
+def test_fused_physics_launch_equals_four_single_substep_launches(near_box):
+    """k_physics4 inlines the sub-step body four times; four k_substep launches run the same body once each.  State after
+    one sim.dt must be bit-identical (the early box solve splits its sweeps around a barrier but performs the same
+    arithmetic sequence; contact forces do not feed back)."""
+    import torch
+    from dexrobot_isaac_amd import _abi
+    from tests.hip_backend import HipBackend
+    n = 192
+    sc, model = _mk("BlindGrasping", n)
+    ms = model.to_struct()
+    a, b = HipBackend(sc, ms), HipBackend(sc, ms)
+    st = _random_state(np.random.default_rng(23), model, n, near_box=near_box)
+    for k, v in st.items():
+        a.set(k, v)
+        b.set(k, v)
+    a.core.run_stage(_abi.STAGE["PHYSICS"])
+    for _ in range(4):
+        b.core.run_stage(_abi.STAGE["SUBSTEP"])
+    torch.cuda.synchronize()
+    for f in ("q", "qd", "box_pos", "box_quat", "box_lin", "box_ang", "site_pose", "ncontact", "cforce"):
+        assert np.array_equal(a.get(f), b.get(f)), f
