@@ -309,7 +309,9 @@ int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream);
 int dexsim_post_physics(dexsim_t h, int obs_only, void* stream);
 
 /* DexHandBase.step (dexhand_base.py:893-942): process_actions, physics, post-physics, in-step resets,
- * conditional extra physics step, extras statistics.  No host synchronisation. */
+ * conditional extra physics step, extras statistics.  No host synchronisation.  With substeps == 4 this is two
+ * launches: one kernel carrying the whole control step up to the reset gate, and its device-gated twin (the extra
+ * physics step + reset phase 1 + statistics); other sub-step counts go through the three staged calls above. */
 int dexsim_step(dexsim_t h, const float* actions, void* stream);
 
 /* DexHandBase.reset_idx (dexhand_base.py:743-803) for caller-chosen envs: env_ids is a device array
@@ -341,14 +343,16 @@ int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, voi
                                  /* action pointer of the last dexsim_step; advances the simulation)                    */
 int dexsim_run_stage(dexsim_t h, int stage, void* stream);
 
-/* Time `launches` back-to-back launches of one stage with hipEvents on `stream`; returns the mean
- * duration in microseconds (used by bench.py for the roofline line). */
+/* Time `launches` launches of one stage, each bracketed by a hipEvent pair and a host synchronisation, and return the
+ * mean duration in microseconds.  The event fences make every launch start from a cold L2, so these are upper bounds
+ * (bench.py uses them for the stand-alone kernels only). */
 int dexsim_time_stage(dexsim_t h, int stage, int launches, void* stream, float* mean_us);
 
 /* In-situ timing of the main launch of dexsim_step (k_physics4 with the action and post-physics blocks when
  * substeps == 4): enable != 0 starts recording a hipEvent pair around that launch on every following dexsim_step
  * (ring of 64, no host synchronisation, so the launches stay back to back as in production); enable == 0 stops,
- * synchronises and returns the mean duration in microseconds over the *n recorded steps.  bench.py's roofline line. */
+ * synchronises and returns the mean duration in microseconds over the *n recorded steps.  (The event fences still
+ * cost the kernel its warm L2: +30 % on MI355X; bench.py therefore times the whole region instead.) */
 int dexsim_step_timing(dexsim_t h, int enable, float* mean_us, int* n);
 
 const char* dexsim_error_string(int code);
