@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""How fast is the physics launch when hands really touch box and ground (general contact path), compared with the
+random-action headline regime where the broadphase clears every workgroup?  Sets the hand base low over the box in all
+envs, lets the contacts develop, and times back-to-back dexsim_physics_step launches (HIP events around the region)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dexrobot_isaac_amd.config import build_sim_config, default_cfg  # noqa: E402
+from dexrobot_isaac_amd.core import DexSimCore  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = default_cfg("BlindGrasping")
+cfg["env"]["numEnvs"] = n
+sc, model = build_sim_config(cfg)
+core = DexSimCore(sc, model.to_struct(), "cuda:0")
+core.reset()
+g = torch.Generator(device="cuda:0").manual_seed(3)
+for label, z in (("hand clear (z offset 0)", 0.0), ("hand low over the box (z offset -0.40)", -0.40), ("pressing (z offset -0.43)", -0.43)):
+    q = core.field("q")
+    q.zero_()
+    q[2] = z
+    q[6:] = 0.3 * torch.rand(20, n, device="cuda:0", generator=g)
+    core.field("qd").zero_()
+    core.field("targets").copy_(q)
+    for _ in range(20):
+        core.physics_step(False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        core.physics_step(False)
+    e1.record()
+    torch.cuda.synchronize()
+    nc = core.field("ncontact").float()
+    print(f"{label}: {e0.elapsed_time(e1) * 10:.1f} us per physics step (4 sub-steps), contacts/env mean {nc.mean().item():.2f} "
+          f"max {int(nc.max().item())}")
