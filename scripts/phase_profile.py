@@ -30,6 +30,16 @@ core.reset()
 a = 2 * torch.rand(n, 18, device="cuda:0") - 1
 for _ in range(10):
     core.step(a)
+if len(sys.argv) > 2:   # contact-rich regime: python scripts/phase_profile.py 4096 -0.40  (hand base lowered onto the box)
+    q = core.field("q")
+    q.zero_()
+    q[2] = float(sys.argv[2])
+    q[6:] = 0.3 * torch.rand(20, n, device="cuda:0")
+    core.field("qd").zero_()
+    core.field("targets").copy_(q)
+    for _ in range(20):
+        core.physics_step(False)
+    print("contact regime: contacts/env mean %.2f max %d" % (core.field("ncontact").float().mean().item(), int(core.field("ncontact").max().item())))
 core.run_stage(_abi.STAGE["SUBSTEP"])
 torch.cuda.synchronize()
 crow = core.field("crow").view(torch.int32).cpu().numpy()      # stamps of lane 0 of every block: rows wv*8 + k
