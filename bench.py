@@ -100,9 +100,10 @@ def main():
 
     def run(k):
         for i in range(k):
+            if rollout is not None:
+                rollout.sink(core)           # this step's obs / rew / done land in the rollout slot: no copy kernels
             core.step(actions[i % n_act])
             if rollout is not None:
-                rollout.add(core.obs_buf, core.rew_buf, core.reset_buf)
                 if rollout.full():
                     # RCCL all-gather over xGMI, once per rollout, overlapped with the next rollout's simulation
                     pending.append(rollout.gather_async())

@@ -178,6 +178,17 @@ class DexSimCore:
     def run_stage(self, stage):
         check(self.lib.dexsim_run_stage(self.h, int(stage), self._stream()), "run_stage")
 
+    def set_step_sink(self, obs=None, rew=None, done=None):
+        """Second destination of the next steps' outputs (rows of a rollout buffer): (N, O) f32, (N,) f32, (N,) u8 tensors
+        on this device, contiguous; None switches a sink off.  The caller keeps the tensors alive."""
+        def ptr(t, dtype, shape):
+            if t is None:
+                return None
+            assert t.is_contiguous() and t.dtype == dtype and tuple(t.shape) == shape and t.device == self.device
+            return C.c_void_p(t.data_ptr())
+        check(self.lib.dexsim_set_step_sink(self.h, ptr(obs, torch.float32, (self.N, int(self.cfg.num_obs))),
+                                            ptr(rew, torch.float32, (self.N,)), ptr(done, torch.uint8, (self.N,))), "set_step_sink")
+
     def step_timing(self, enable):
         """Start (True) / stop (False) the in-situ hipEvent timing of dexsim_step's main launch; stop returns (mean_us, n)."""
         us, n = C.c_float(0.0), C.c_int(0)

@@ -510,6 +510,12 @@ int dexsim_time_stage(dexsim_t h, int stage, int launches, void* stream, float* 
   return DEXSIM_OK;
 }
 
+int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done) {
+  if (!h) return fail(DEXSIM_ERR_ARG, "null handle");
+  h->api.sink_obs = obs; h->api.sink_rew = rew; h->api.sink_done = done;   // kernel arguments: effective from the next launch
+  return DEXSIM_OK;
+}
+
 int dexsim_step_timing(dexsim_t h, int enable, float* mean_us, int* n) {
   NEED_BOUND(h);
   if (enable) {

@@ -58,6 +58,18 @@ class RolloutBuffer:
         s.done[self.t].copy_(done)
         self.t += 1
 
+    def sink(self, core):
+        """Copy-free variant of add(): point the simulator's step sink (dexsim_set_step_sink) at row t of the slot being
+        filled and advance; call BEFORE core.step().  The step's flush then writes obs / rew / done straight into the
+        rollout buffer."""
+        if self.t >= self.T:
+            raise RuntimeError("rollout buffer full: call gather()/gather_async()/clear() first")
+        s = self.slots[self.cur]
+        if self.t == 0:
+            self._wait(s)
+        core.set_step_sink(s.obs[self.t], s.rew[self.t], s.done[self.t])
+        self.t += 1
+
     def clear(self):
         self.t = 0
 

@@ -330,6 +330,13 @@ int dexsim_refresh_body_states(dexsim_t h, void* stream);
 int dexsim_set_dof_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream);
 int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream);
 
+/* Rollout sink (new capability, SURVEY.md 8e / 8f-1: the "PPO buffer" end of the path): besides obs_buf / rew_buf /
+ * reset_buf the post-physics flush of every following dexsim_step / dexsim_post_physics also writes the step's
+ * observations (N, num_obs) f32, rewards (N) f32 and done flags (N) u8 to these device pointers -- typically row t of
+ * the caller's (T, N, ...) rollout tensors -- so that collecting a rollout needs no copy kernels.  Any pointer may be
+ * NULL; all NULL switches the sink off.  The pointers are kernel arguments: no device memory is touched by this call. */
+int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done);
+
 /* Test / profiling hooks: run one pipeline stage on the bound buffers. */
 #define DEXSIM_STAGE_DYNAMICS 0  /* FK + CRBA + bias + factorisation + narrowphase + row build (stand-alone kernel) */
 #define DEXSIM_STAGE_SOLVE    1  /* PGS contact-impulse solve + integrate (stand-alone kernel)      */

@@ -443,3 +443,32 @@ def test_fused_physics_launch_equals_four_single_substep_launches(near_box):
     torch.cuda.synchronize()
     for f in ("q", "qd", "box_pos", "box_quat", "box_lin", "box_ang", "site_pose", "ncontact", "cforce"):
         assert np.array_equal(a.get(f), b.get(f)), f
+
+
+def test_step_sink_writes_rollout_rows():
+    """dexsim_set_step_sink / RolloutBuffer.sink: the step's flush writes obs, reward and done also into the rollout slot."""
+    import torch
+    from dexrobot_isaac_amd.core import DexSimCore
+    from dexrobot_isaac_amd.rollout import RolloutBuffer
+    n = 200                                              # not a multiple of 64: exercises the partial last workgroup
+    sc, model = _mk("BlindGrasping", n, **{"env.episodeLength": 6})
+    core = DexSimCore(sc, model.to_struct(), "cuda:0")
+    core.reset()
+    rb = RolloutBuffer(8, n, int(sc.num_obs), "cuda:0")
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    for t in range(8):
+        a = 2 * torch.rand(n, 18, device="cuda:0", generator=g) - 1
+        rb.sink(core)
+        core.step(a)
+        torch.cuda.synchronize()
+        assert torch.equal(rb.slots[0].obs[t], core.obs_buf)
+        assert torch.equal(rb.slots[0].rew[t], core.rew_buf)
+        assert torch.equal(rb.slots[0].done[t].bool(), core.reset_buf.bool())
+    assert rb.full() and int(rb.slots[0].done.sum()) > 0   # timeouts at step 5 really reached the sink
+    obs, rew, done = rb.gather()
+    assert obs.shape == (8, n, int(sc.num_obs))
+    core.set_step_sink(None, None, None)
+    before = rb.slots[0].obs[7].clone()
+    core.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(rb.slots[0].obs[7], before)
