@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--task", default="BlindGrasping", choices=["BlindGrasping", "BaseTask"],
                     help="BaseTask + --control-mode position + --num-envs 1024 = BASELINE configs[1] (articulated FD only, no object)")
     ap.add_argument("--control-mode", default=None, choices=["position", "position_delta"])
+    ap.add_argument("--rollout", action="store_true", help="fill the rollout buffer also when --gpus 1 (the multi-GPU code path minus the collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", action="store_true", help="skip the secondary staggered-episode measurement")
     args = ap.parse_args()
@@ -94,7 +95,7 @@ def main():
     gen.manual_seed(1234 + rank)
     n_act = 64                               # distinct pre-generated action batches, cycled
     actions = 2.0 * torch.rand(n_act, N, 18, device=device, generator=gen) - 1.0
-    rollout = RolloutBuffer(args.horizon, N, sc.num_obs, device) if world > 1 else None
+    rollout = RolloutBuffer(args.horizon, N, sc.num_obs, device) if (world > 1 or args.rollout) else None
 
     pending = []
 
@@ -205,6 +206,8 @@ def main():
             k = torch.randint(0, 199, es.shape, device=device, generator=gen)
             es.copy_(k.to(es.dtype))
             tis.copy_(k.to(tis.dtype) * float(sc.control_dt))
+            rollout = None                   # (the secondary figure is measured without the rollout sink)
+            core.set_step_sink(None, None, None)
             run(50)
             r0 = float(core.field("reset_count").sum().item())
             torch.cuda.synchronize()
