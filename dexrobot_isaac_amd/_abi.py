@@ -109,7 +109,7 @@ EXPORTED_SYMBOLS = [
     "dexsim_body_name", "dexsim_create", "dexsim_destroy", "dexsim_bind", "dexsim_init_state",
     "dexsim_process_actions", "dexsim_physics_step", "dexsim_post_physics", "dexsim_step",
     "dexsim_reset_idx", "dexsim_reset", "dexsim_refresh_body_states", "dexsim_set_dof_state_indexed",
-    "dexsim_set_root_state_indexed", "dexsim_run_stage", "dexsim_time_stage", "dexsim_step_timing", "dexsim_set_step_sink", "dexsim_error_string",
+    "dexsim_set_root_state_indexed", "dexsim_run_stage", "dexsim_time_stage", "dexsim_step_timing", "dexsim_set_step_sink", "dexsim_set_action_copy", "dexsim_error_string",
     "dexsim_last_error",
 ]
 
@@ -140,6 +140,7 @@ def declare_prototypes(lib):
     lib.dexsim_time_stage.argtypes = [vp, i32, i32, vp, P(f32)]
     lib.dexsim_step_timing.argtypes = [vp, i32, P(f32), P(i32)]
     lib.dexsim_set_step_sink.argtypes = [vp, vp, vp, vp]
+    lib.dexsim_set_action_copy.argtypes = [vp, vp]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name).restype = i32
     lib.dexsim_error_string.argtypes = [i32]

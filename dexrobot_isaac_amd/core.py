@@ -189,6 +189,14 @@ class DexSimCore:
         check(self.lib.dexsim_set_step_sink(self.h, ptr(obs, torch.float32, (self.N, int(self.cfg.num_obs))),
                                             ptr(rew, torch.float32, (self.N,)), ptr(done, torch.uint8, (self.N,))), "set_step_sink")
 
+    def set_action_copy(self, dst):
+        """(N, num_actions) f32 tensor that receives a copy of every step's actions (DexHandBase.actions), or None."""
+        if dst is not None:
+            assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.device == self.device
+            assert tuple(dst.shape) == (self.N, int(self.cfg.num_actions))
+        self._actions_copy = dst
+        check(self.lib.dexsim_set_action_copy(self.h, None if dst is None else C.c_void_p(dst.data_ptr())), "set_action_copy")
+
     def step_timing(self, enable):
         """Start (True) / stop (False) the in-situ hipEvent timing of dexsim_step's main launch; stop returns (mean_us, n)."""
         us, n = C.c_float(0.0), C.c_int(0)

@@ -516,6 +516,12 @@ int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done) {
   return DEXSIM_OK;
 }
 
+int dexsim_set_action_copy(dexsim_t h, float* dst) {
+  if (!h) return fail(DEXSIM_ERR_ARG, "null handle");
+  h->api.actions_copy = dst;
+  return DEXSIM_OK;
+}
+
 int dexsim_step_timing(dexsim_t h, int enable, float* mean_us, int* n) {
   NEED_BOUND(h);
   if (enable) {

@@ -333,6 +333,9 @@ class DexHandEnv:
         self.rew_buf, self.reset_buf = core.rew_buf, core.reset_buf
         self.episode_step_count = core.episode_step_count
         self.actions = torch.zeros((self.num_envs, self._num_actions), device=self.device)
+        self._actions_copy_bound = hasattr(core, "set_action_copy")     # (the CPU oracle stand-in of the tests has no sink)
+        if self._actions_copy_bound:
+            core.set_action_copy(self.actions)
         self.dof_state = core.dof_state
         self.dof_pos, self.dof_vel = core.dof_state[..., 0], core.dof_state[..., 1]
         self.actor_root_state_tensor = core.root_state
@@ -456,8 +459,18 @@ class DexHandEnv:
         """obs (N,O) f32, rew (N,) f32, done (N,) bool, extras -- views of env-owned buffers."""
         if actions is None:
             raise RuntimeError("Actions cannot be None")
-        self.actions = actions.clone()                           # dexhand_base.py:851
         ap = self.action_processor
+        fused = not ap._host_path() and ap._action_rule is None
+        if fused and self._actions_copy_bound:
+            # DexHandBase.actions = actions.clone() (dexhand_base.py:851): the copy is written by the action block of the
+            # step kernel itself (dexsim_set_action_copy) into self.actions -- no clone launch on the hot path
+            self._core.step(actions)
+            self._apply_pre_action_rule()
+            return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+        if self._actions_copy_bound:
+            self.actions.copy_(actions)      # keep the tensor the device copy is bound to
+        else:
+            self.actions = actions.clone()                       # dexhand_base.py:851
         if ap._host_path():
             # custom post-action filter / coupling rule: action stage in torch on the host, then the staged device path
             ap._host_process_actions(self.actions)

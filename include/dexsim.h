@@ -337,6 +337,11 @@ int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, voi
  * NULL; all NULL switches the sink off.  The pointers are kernel arguments: no device memory is touched by this call. */
 int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done);
 
+/* DexHandBase.pre_physics_step keeps `self.actions = actions.clone()` (dexhand_base.py:851).  With a destination set here
+ * ((N, num_actions) f32 on the device, or NULL to switch off) the action block writes that copy itself, so the host side
+ * needs no clone kernel per step.  Kernel argument like the step sink. */
+int dexsim_set_action_copy(dexsim_t h, float* dst);
+
 /* Test / profiling hooks: run one pipeline stage on the bound buffers. */
 #define DEXSIM_STAGE_DYNAMICS 0  /* FK + CRBA + bias + factorisation + narrowphase + row build (stand-alone kernel) */
 #define DEXSIM_STAGE_SOLVE    1  /* PGS contact-impulse solve + integrate (stand-alone kernel)      */

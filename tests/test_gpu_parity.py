@@ -445,6 +445,23 @@ def test_fused_physics_launch_equals_four_single_substep_launches(near_box):
         assert np.array_equal(a.get(f), b.get(f)), f
 
 
+def test_env_actions_copy_written_by_the_step_kernel():
+    """env.actions (DexHandBase.actions = actions.clone()) is filled by the action block of the step kernel."""
+    import torch
+    from dexrobot_isaac_amd import make_env
+    from dexrobot_isaac_amd.config import default_cfg
+    cfg = default_cfg("BlindGrasping")
+    cfg["env"]["numEnvs"] = 100
+    env = make_env("BlindGrasping", 100, "cuda:0", "cuda:0", 0, cfg=cfg)
+    env.reset()
+    a = 2 * torch.rand(100, 18, device="cuda:0") - 1
+    keep = a.clone()
+    env.step(a)
+    a.zero_()                                  # the caller may reuse its tensor right away
+    torch.cuda.synchronize()
+    assert torch.equal(env.actions, keep)
+
+
 def test_step_sink_writes_rollout_rows():
     """dexsim_set_step_sink / RolloutBuffer.sink: the step's flush writes obs, reward and done also into the rollout slot."""
     import torch
