@@ -2,59 +2,43 @@
 """bench.py -- env-steps/sec of random-action BlindGrasping at num_envs=4096 per GPU (BASELINE.json metric,
 configs[2] at N=1; configs[3] = the same sharded over N GPUs, weak scaling).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1 without WORLD_SIZE: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one env.step() for every env of the rank: action processing, one physics step (4 sub-steps of
 dynamics + PGS contact solve), fused obs/reward/termination, in-step resets and the reference's conditional
 extra physics step -- nothing is skipped.  Synthetic data: random actions 2*U(0,1)-1 (the law of the
 reference's random-action mode, dexhand_base.py:856), pre-generated in HBM before the timed region.
+
+Besides the contract line's `value` the JSON carries three secondary regimes that are never `value`:
+`staggered_resets` (episode clocks de-synchronised: some env resets in almost every step, as in training),
+`contact_rich` (every hand lowered onto its box: the regime a grasping policy lives in, with the contact-solve
+roofline measured there) and `cpu_baseline` (the CPU oracle on the host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-
-def cpu_baseline(sim_cfg_factory, seconds_budget=20.0):
-    """The CPU oracle (scalar restatement of the same algorithm; 'port', not PhysX) on the host cores,
-    bounded sample of the same workload."""
-    import numpy as np
-    from oracle.oracle import Oracle
-    n = 1024
-    sc, model = sim_cfg_factory(n)
-    best = None
-    avail = len(os.sched_getaffinity(0))
-    for cores in sorted({4, min(avail, 16)}):
-        o = Oracle(sc, model.to_struct(), threads=cores)
-        o.reset()
-        rng = np.random.default_rng(1234)
-        acts = [(2 * rng.random((n, 18)) - 1).astype(np.float32) for _ in range(4)]
-        o.step(acts[0])
-        t0, k = time.time(), 0
-        while time.time() - t0 < seconds_budget / 2 and k < 40:
-            o.step(acts[k % 4])
-            k += 1
-        v = n * k / (time.time() - t0)
-        if best is None or v > best["value"]:
-            best = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
-                    "sample": f"BlindGrasping N={n}, {k} control steps, random actions, oracle/dexsim_oracle.c with OpenMP"}
-    return best
+PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+STEP_BYTES = 2560.0                        # SURVEY.md 8d: algorithmic bytes of a whole env-step
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--horizon", type=int, default=16, help="rollout length between RCCL gathers (gpus > 1)")
+    ap.add_argument("--gather", default="learner", choices=["learner", "all"],
+                    help="end-of-rollout collective: gather to the learner rank (default) or all-gather")
     ap.add_argument("--dr", action="store_true", help="BASELINE config #5: per-env box mass/friction randomisation")
     ap.add_argument("--task", default="BlindGrasping", choices=["BlindGrasping", "BaseTask"],
                     help="BaseTask + --control-mode position + --num-envs 1024 = BASELINE configs[1] (articulated FD only, no object)")
@@ -62,19 +46,75 @@ def main():
     ap.add_argument("--rollout", action="store_true", help="fill the rollout buffer also when --gpus 1 (the multi-GPU code path minus the collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", action="store_true", help="skip the secondary staggered-episode measurement")
-    args = ap.parse_args()
+    ap.add_argument("--no-contact-rich", action="store_true", help="skip the secondary contact-rich measurement")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as child processes (one per GPU,
+    torch.distributed.run) BEFORE this process touches the GPU, and exit with the launcher's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def cpu_baseline(sim_cfg_factory, n, seconds_budget=24.0):
+    """The CPU oracle (scalar restatement of the same algorithm; 'port', not PhysX) on the host cores: same config,
+    same action law, N = the benchmark's num_envs, on 4 threads (the reference's physx.num_threads,
+    cfg/physics/default.yaml:20) and on all cores; bounded sample."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    sc, model = sim_cfg_factory(n)
+    avail = len(os.sched_getaffinity(0))
+    runs = {}
+    for cores in sorted({min(4, avail), avail}):
+        o = Oracle(sc, model.to_struct(), threads=cores)
+        o.reset()
+        rng = np.random.default_rng(1234)
+        acts = [(2 * rng.random((n, 18)) - 1).astype(np.float32) for _ in range(4)]
+        o.step(acts[0])
+        t0, k = time.time(), 0
+        while time.time() - t0 < seconds_budget / 2 and k < 200:
+            o.step(acts[k % 4])
+            k += 1
+        runs[cores] = {"value": n * k / (time.time() - t0), "control_steps": k}
+    best = max(runs)
+    return {"value": runs[best]["value"], "unit": "env-steps/s", "cores": best, "kind": "port",
+            "sample": f"BlindGrasping N={n}, {runs[best]['control_steps']} control steps, random actions, "
+                      "oracle/dexsim_oracle.c with OpenMP (CPU restatement -- not PhysX; baseline, not target)",
+            "threads_4": {"value": runs[min(runs)]["value"], "cores": min(runs), "control_steps": runs[min(runs)]["control_steps"]},
+            "host_cores_available": avail}
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        self_launch(args)
+    world = int(world_env or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+              f"(python bench.py --gpus N starts them itself)", file=sys.stderr)
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
     import torch.distributed as dist
     from dexrobot_isaac_amd import _abi
     from dexrobot_isaac_amd.config import build_sim_config, default_cfg
     from dexrobot_isaac_amd.core import DexSimCore
     from dexrobot_isaac_amd.rollout import RolloutBuffer
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -95,7 +135,7 @@ def main():
     gen.manual_seed(1234 + rank)
     n_act = 64                               # distinct pre-generated action batches, cycled
     actions = 2.0 * torch.rand(n_act, N, 18, device=device, generator=gen) - 1.0
-    rollout = RolloutBuffer(args.horizon, N, sc.num_obs, device) if (world > 1 or args.rollout) else None
+    rollout = RolloutBuffer(args.horizon, N, sc.num_obs, device, mode=args.gather) if (world > 1 or args.rollout) else None
 
     pending = []
 
@@ -106,7 +146,7 @@ def main():
             core.step(actions[i % n_act])
             if rollout is not None:
                 if rollout.full():
-                    # RCCL all-gather over xGMI, once per rollout, overlapped with the next rollout's simulation
+                    # RCCL gather over xGMI, once per rollout, overlapped with the next rollout's simulation
                     pending.append(rollout.gather_async())
                     if len(pending) > 1:
                         pending.pop(0)()     # the previous rollout's gather must have landed by now
@@ -134,28 +174,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     resets = float(core.field("reset_count").sum().item()) - resets0
+    kbar = float(core.stats[_abi.STAT["MEAN_CONTACTS"]].item())
+    kbar_hand = float(core.stats[_abi.STAT["MEAN_HAND_CONTACTS"]].item())
+
+    collective = None
+    if world > 1:
+        # the end-of-rollout collective on its own (not overlapped), next to the simulation time of one rollout
+        tms = []
+        for _ in range(5):
+            rollout.t = rollout.T
+            torch.cuda.synchronize()
+            dist.barrier()
+            c0 = time.perf_counter()
+            rollout.gather()
+            torch.cuda.synchronize()
+            tms.append((time.perf_counter() - c0) * 1e3)
+        tt = torch.tensor([sorted(tms)[len(tms) // 2]], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        per_rank_mb = args.horizon * N * (sc.num_obs * 4 + 4 + 1) / 1e6
+        collective = {"mode": args.gather, "collective_ms": float(tt.item()),
+                      "simulation_ms_per_rollout": dt / args.steps * 1e3 * args.horizon,
+                      "payload_mb_per_rank": per_rank_mb, "rccl_ranks": dist.get_world_size(),
+                      "note": "collective_ms = blocking gather alone (median of 5, max over ranks); in the timed region it is "
+                              "issued asynchronously and overlaps the next rollout (double-buffered slots)"}
 
     if rank == 0:
         total_envs = N * world
         value = total_envs * args.steps / dt
-        # live per-kernel timing with HIP events on the launch stream (one launch = one sub-step of all envs)
-        kbar = float(core.stats[_abi.STAT["MEAN_CONTACTS"]].item())
         # The production launch (k_physics4<false>: actions + 4 sub-steps + post-physics) is issued once per control step,
-        # so its mean duration over the timed region = GPU time between the two HIP events / steps, minus nothing: the
-        # figure therefore also contains the device-gated no-op launch (~3 us) and the dispatch gaps -- an upper bound.
-        # A hipEvent pair around each single launch is NOT used: the event's release/acquire fences make the kernel
-        # start from a cold L2 (rocprofv3 shows 125 us instead of 94 us for such launches, profiles/round1_d_*).
+        # so its mean duration over the timed region = GPU time between the two HIP events / steps: the figure also
+        # contains the device-gated no-op launch (~3 us) and the dispatch gaps -- an upper bound.  A hipEvent pair around
+        # each single launch is NOT used: the events' release/acquire fences make the kernel start from a cold L2.
         t_step = ev0.elapsed_time(ev1) * 1e3 / args.steps
         t_sub = core.time_stage(_abi.STAGE["SUBSTEP"], 50)     # a single sub-step (dynamics + solve + integrate + publish) as its own launch
         t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)     # the same sweeps as a stand-alone kernel
         t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)
         t_post = core.time_stage(_abi.STAGE["POST"], 20)
         t_pub = core.time_stage(_abi.STAGE["PUBLISH"], 20)
-        peak = 8000.0
-        step_bytes = 2560.0                            # algorithmic bytes of a whole env-step
-        # algorithmic HBM bytes per env per launch
         b_sub = (632.0 + 204.0) * N                    # q, qd, targets, box in; q, qd, box out; cforce (last sub-step)
-        b_solve = (256.0 + 60.0 * kbar) * N
         b_dyn = (500.0 + 36.0 * kbar) * N
         pmc = {}
         try:                                           # HBM traffic from the separate rocprofv3 --pmc passes
@@ -163,15 +219,17 @@ def main():
         except Exception:
             pass
 
-        def roof(kernel, bytes_, us):
+        def roof(kernel, bytes_, us, contacts=kbar, limited_by="dependent-issue latency (per-env sequential fp32 math)"):
             a = bytes_ / (us * 1e-6) / 1e9
             tr = None
             rec = pmc.get(kernel)
             if rec and int(rec.get("num_envs", -1)) == N:
                 # gfx950: FETCH_SIZE tallies 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); counters are in KB
                 tr = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0
-            return {"bound": "hbm", "achieved": a, "peak": peak, "unit": "GB/s", "frac": a / peak, "traffic": tr,
-                    "kernel": kernel, "avg_us": us, "algorithmic_bytes": bytes_, "mean_contacts": kbar}
+            # "bound" names the nominal roofline the fraction is taken against (HBM); at these fractions the
+            # kernels are not bandwidth-bound -- `limited_by` says what actually limits them
+            return {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS, "traffic": tr,
+                    "kernel": kernel, "avg_us": us, "algorithmic_bytes": bytes_, "mean_contacts": contacts, "limited_by": limited_by}
 
         out = {
             "metric": f"env-steps/sec {args.task} num_envs={N} per MI355X (random actions)",
@@ -183,22 +241,28 @@ def main():
                        "control_mode": args.control_mode or "task default",
                        "num_envs_per_gpu": N, "sim_dt": 0.01, "substeps": 4, "pgs_iterations": 16,
                        "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
+                       "rollout_gather_mode": args.gather if world > 1 else None,
                        "domain_randomisation": bool(args.dr)},
             "resets_per_step": resets / args.steps,
+            # the headline regime's contact set: random actions from the spawn pose never bring a finger to the box, so
+            # these are the box's corners on the ground (see contact_rich for the regime the solver exists for)
+            "mean_contacts": {"total": kbar, "hand": kbar_hand, "box_ground": kbar - kbar_hand},
             # dominant kernel = the one launch that carries a whole control step (k_physics4<false> with the action and
             # post-physics blocks); algorithmic bytes = SURVEY 8d's whole-env-step figure
-            "roofline": roof("k_physics4", step_bytes * N, t_step),
+            "roofline": roof("k_physics4", STEP_BYTES * N, t_step),
             "roofline_substep": roof("k_substep", b_sub, t_sub),
-            "roofline_contact_solve": roof("k_solve", b_solve, t_solve),
+            "roofline_contact_solve": roof("k_solve", (256.0 + 60.0 * kbar) * N, t_solve),
             "roofline_dynamics": roof("k_dynamics", b_dyn, t_dyn),
-            "roofline_whole_step": {"bound": "hbm", "achieved": step_bytes * value / world / 1e9, "peak": peak,
-                                    "unit": "GB/s", "frac": step_bytes * value / world / 1e9 / peak, "traffic": None},
+            "roofline_whole_step": {"bound": "hbm", "achieved": STEP_BYTES * value / world / 1e9, "peak": PEAK_HBM_GBS,
+                                    "unit": "GB/s", "frac": STEP_BYTES * value / world / 1e9 / PEAK_HBM_GBS, "traffic": None},
             "kernel_us": {"k_physics4_step": t_step, "k_substep": t_sub, "k_dynamics": t_dyn, "k_solve": t_solve, "k_post": t_post, "k_publish": t_pub},
         }
+        if collective is not None:
+            out["rollout_gather"] = collective
         if world == 1 and not args.no_stagger:
             # Secondary figure, NOT `value`: the timed region above starts from a fresh env, like the reference's own run,
-            # so all episodes time out in the same control step and the conditional second physics step of
-            # reset_manager.py:180 runs once per ~300 steps.  In training the episodes de-synchronise and some env
+            # so all episodes end in the same control step and the conditional second physics step of
+            # reset_manager.py:180 runs once per ~200 steps.  In training the episodes de-synchronise and some env
             # resets in (almost) every control step; this run staggers the episode clocks to show that regime.
             # (random actions end every episode through the stage-1 pre-grasp check at t = 4 s = 200 control steps, so the
             # stage clock and the episode clock are staggered together)
@@ -206,7 +270,7 @@ def main():
             k = torch.randint(0, 199, es.shape, device=device, generator=gen)
             es.copy_(k.to(es.dtype))
             tis.copy_(k.to(tis.dtype) * float(sc.control_dt))
-            rollout = None                   # (the secondary figure is measured without the rollout sink)
+            rollout = None                   # (the secondary figures are measured without the rollout sink)
             core.set_step_sink(None, None, None)
             run(50)
             r0 = float(core.field("reset_count").sum().item())
@@ -217,8 +281,47 @@ def main():
             ds = time.perf_counter() - ts
             out["staggered_resets"] = {"value": N * 200 / ds, "unit": "env-steps/s", "ms_per_step": ds / 200 * 1e3,
                                        "resets_per_step": (float(core.field("reset_count").sum().item()) - r0) / 200}
+        if world == 1 and not args.no_contact_rich and args.task == "BlindGrasping":
+            # Secondary figure, NOT `value`: every hand lowered onto its box (scripts/contact_regime.py's state) -- the
+            # regime a policy that has learnt to grasp lives in.  Timed: back-to-back physics steps (4 sub-steps each,
+            # general contact path in every workgroup), HIP events around the region; and the stand-alone contact-solve
+            # kernel in that state for the BASELINE sub-metric "contact-solve HBM %".
+            q = core.field("q")
+            q.zero_()
+            q[2] = -0.40
+            q[6:] = 0.3 * torch.rand(20, N, device=device, generator=gen)
+            core.field("qd").zero_()
+            core.field("targets").copy_(q)
+            for _ in range(20):
+                core.physics_step(False)
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(50):
+                core.physics_step(False)
+            c1.record()
+            torch.cuda.synchronize()
+            us_phys = c0.elapsed_time(c1) * 1e3 / 50
+            nc = core.field("ncontact").float()
+            k_mean, k_max = float(nc.mean().item()), int(nc.max().item())
+            code = core.field("ccode")
+            kidx = torch.arange(code.shape[0], device=device)[:, None]
+            hand = float((((code & 3) != 2) & (kidx < core.field("ncontact"))).sum().item()) / N
+            t_solve_c = core.time_stage(_abi.STAGE["SOLVE"], 30)
+            out["contact_rich"] = {
+                "state": "hand base lowered 0.40 m onto the box in every env, fingers at U(0,0.3) rad, targets = pose; 20 physics steps to develop the contacts",
+                "us_per_physics_step": us_phys, "env_steps_per_s_physics_only": N / (us_phys * 1e-6),
+                "mean_contacts": {"total": k_mean, "hand": hand, "box_ground": k_mean - hand}, "max_contacts": k_max,
+                "roofline_contact_solve": roof("k_solve", (256.0 + 60.0 * k_mean) * N, t_solve_c, contacts=k_mean,
+                                               limited_by="sequential Gauss-Seidel sweeps (16 x K contact updates per lane)"),
+                # the same figure for the fused production path: 4 sub-steps per physics step, solver bytes only
+                "roofline_contact_solve_fused": {"bound": "hbm", "achieved": (256.0 + 60.0 * k_mean) * N * 4 / (us_phys * 1e-6) / 1e9,
+                                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                 "frac": (256.0 + 60.0 * k_mean) * N * 4 / (us_phys * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                                                 "note": "upper bound on the solver's share: the whole physics step's time is charged to it"},
+            }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(factory)
+            out["cpu_baseline"] = cpu_baseline(factory, N)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -20,11 +20,10 @@ NUM_MASKS = 3 + NUM_SUCC + NUM_FAIL
 MASK_SUCCESS, MASK_FAILURE, MASK_TIMEOUT, MASK_SUCC_REASON, MASK_FAIL_REASON = 0, 1, 2, 3, 3 + NUM_SUCC
 STAT_WORDS = 64
 STAT = dict(SUCC_MEAN=0, FAIL_MEAN=4, SUCCESS_RATE=12, FAILURE_RATE=13, TIMEOUT_RATE=14,
-            CONSECUTIVE_SUCCESSES=15, NUM_RESETS=16, PHYSICS_STEPS=17, MEAN_CONTACTS=18)
+            CONSECUTIVE_SUCCESSES=15, NUM_RESETS=16, PHYSICS_STEPS=17, MEAN_CONTACTS=18, MEAN_HAND_CONTACTS=19)
 
 TASK_BASE, TASK_BLIND_GRASPING = 0, 1
 MODE_POSITION, MODE_POSITION_DELTA = 0, 1
-CNT_ANY_RESET, CNT_CONTACTS = 0, 12   # dexsim_device.h: device-side control flags inside the counters block
 STAGE = dict(DYNAMICS=0, SOLVE=1, PUBLISH=2, POST=3, RESET=4, FINALIZE=5, SUBSTEP=6, PHYSICS=7, STEP=8)
 
 SUCCESS_CRITERIA = ["grasp_lift_success"]
@@ -107,7 +106,7 @@ class DexSimBuffers(C.Structure):
 EXPORTED_SYMBOLS = [
     "dexsim_struct_sizes", "dexsim_arena_layout", "dexsim_obs_key_info", "dexsim_reward_term_name",
     "dexsim_body_name", "dexsim_create", "dexsim_destroy", "dexsim_bind", "dexsim_init_state",
-    "dexsim_process_actions", "dexsim_physics_step", "dexsim_post_physics", "dexsim_step",
+    "dexsim_process_actions", "dexsim_begin_step", "dexsim_physics_step", "dexsim_post_physics", "dexsim_step",
     "dexsim_reset_idx", "dexsim_reset", "dexsim_refresh_body_states", "dexsim_set_dof_state_indexed",
     "dexsim_set_root_state_indexed", "dexsim_run_stage", "dexsim_time_stage", "dexsim_step_timing", "dexsim_set_step_sink", "dexsim_set_action_copy", "dexsim_error_string",
     "dexsim_last_error",
@@ -128,6 +127,7 @@ def declare_prototypes(lib):
     lib.dexsim_bind.argtypes = [vp, P(DexSimBuffers)]
     lib.dexsim_init_state.argtypes = [vp, vp]
     lib.dexsim_process_actions.argtypes = [vp, vp, i32, vp]
+    lib.dexsim_begin_step.argtypes = [vp, vp]
     lib.dexsim_physics_step.argtypes = [vp, i32, vp]
     lib.dexsim_post_physics.argtypes = [vp, i32, vp]
     lib.dexsim_step.argtypes = [vp, vp, vp]

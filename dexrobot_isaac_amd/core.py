@@ -142,10 +142,9 @@ class DexSimCore:
         check(self.lib.dexsim_process_actions(self.h, self._actions_ptr(actions), int(zero_targets), self._stream()), "process_actions")
 
     def begin_step(self):
-        """Clear the per-step device flags (what k_actions does at the start of a control step); used when the action
-        stage ran on the host."""
-        self.counters[_abi.CNT_ANY_RESET] = 0
-        self.counters[_abi.CNT_CONTACTS] = 0
+        """Open a control step whose action stage ran on the host (what dexsim_process_actions does for the device-side
+        step bookkeeping: new reset-gate stamp, contact statistics words)."""
+        check(self.lib.dexsim_begin_step(self.h, self._stream()), "begin_step")
 
     def physics_step(self, gate_on_reset=False):
         check(self.lib.dexsim_physics_step(self.h, int(gate_on_reset), self._stream()), "physics_step")
@@ -186,6 +185,7 @@ class DexSimCore:
                 return None
             assert t.is_contiguous() and t.dtype == dtype and tuple(t.shape) == shape and t.device == self.device
             return C.c_void_p(t.data_ptr())
+        self._sink_obs = obs                 # (env.py patches a custom pre-action rule's output into the sink row)
         check(self.lib.dexsim_set_step_sink(self.h, ptr(obs, torch.float32, (self.N, int(self.cfg.num_obs))),
                                             ptr(rew, torch.float32, (self.N,)), ptr(done, torch.uint8, (self.N,))), "set_step_sink")
 

@@ -48,6 +48,19 @@ struct DexSim {
 
 static int padded(int n) { return (n + 63) / 64 * 64; }
 
+// A new control step begins: new stamp for the device-side reset gate and the parity of the contact statistics (CNT_ANY_RESET,
+// CNT_CONTACTS in dexsim_device.h).  Never 0 (the counters block is zero-initialised).
+static void next_stamp(DexSim* h) { h->api.stamp = h->api.stamp >= 0x3ffffffe ? 1 : h->api.stamp + 1; }
+
+// Every entry point runs on the handle's device whatever the caller's current device is, and restores the caller's.
+struct DeviceGuard {
+  int prev = -1; bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 static const char* const kObsKeyNames[] = {
 #define X(name, dim) #name,
     DEXSIM_OBS_KEYS(X)
@@ -169,9 +182,22 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DEXSIM_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(DEXSIM_ERR_NO_DEVICE, "device index out of range");
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard guard(device);
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device) return fail(DEXSIM_ERR_HIP, "dexsim_create: cannot select the device");
   DexSim* h = new DexSim();
+  struct Cleanup {   // a failure below must not leak the handle, the parameter block or the events
+    DexSim* h; bool armed = true;
+    ~Cleanup() {
+      if (!armed) return;
+      if (h->d_params) (void)hipFree(h->d_params);
+      if (h->ev0) (void)hipEventDestroy(h->ev0);
+      if (h->ev1) (void)hipEventDestroy(h->ev1);
+      delete h;
+    }
+  } cleanup{h};
   h->cfg = *cfg; h->model = *model; h->device = device;
+  h->api.stamp = 1;
   h->N = cfg->num_envs; h->NS = padded(cfg->num_envs);
   h->bound = false;
   DevParams hp;
@@ -244,13 +270,14 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_physics4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
+  cleanup.armed = false;
   *out = h;
   return DEXSIM_OK;
 }
 
 int dexsim_destroy(dexsim_t h) {
   if (!h) return DEXSIM_OK;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   (void)hipFree(h->d_params);
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
@@ -261,6 +288,7 @@ int dexsim_destroy(dexsim_t h) {
 
 int dexsim_bind(dexsim_t h, const DexSimBuffers* b) {
   if (!h || !b) return fail(DEXSIM_ERR_ARG, "dexsim_bind: null argument");
+  DeviceGuard guard(h->device);
   if (!b->arena || !b->stats || !b->counters || !b->obs_buf || !b->rew_buf || !b->reset_buf || !b->episode_step_count ||
       !b->episode_length || !b->dof_state || !b->root_state)
     return fail(DEXSIM_ERR_ARG, "dexsim_bind: arena, stats, counters, obs_buf, rew_buf, reset_buf, episode_step_count, "
@@ -287,7 +315,8 @@ int dexsim_bind(dexsim_t h, const DexSimBuffers* b) {
 
 #define NEED_BOUND(h)                                                        \
   if (!(h)) return fail(DEXSIM_ERR_ARG, "null handle");                      \
-  if (!(h)->bound) return fail(DEXSIM_ERR_NOT_BOUND, "dexsim_bind has not been called")
+  if (!(h)->bound) return fail(DEXSIM_ERR_NOT_BOUND, "dexsim_bind has not been called"); \
+  DeviceGuard _device_guard((h)->device)
 #define GRID(h) dim3((h)->NS / 64), dim3(64), 0, (hipStream_t)stream
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
@@ -306,8 +335,8 @@ static size_t solve_lds_bytes(int kstage) { return (size_t)SOLVE_LDS_WORDS(kstag
 static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
   const int ks = solve_kstage(h);
   const size_t lds = solve_lds_bytes(ks);
-  if (gate) k_solve<true><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, ks, h->NS);
-  else k_solve<false><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, last, ks, h->NS);
+  if (gate) k_solve<true><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, last, ks, h->NS);
+  else k_solve<false><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, last, ks, h->NS);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
@@ -324,8 +353,8 @@ static int launch_substep(dexsim_t h, int gate, int last, void* stream) {
   return DEXSIM_OK;
 }
 static int launch_dynamics(dexsim_t h, int gate, void* stream) {
-  if (gate) k_dynamics<true><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->NS);
-  else k_dynamics<false><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->NS);
+  if (gate) k_dynamics<true><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, h->NS);
+  else k_dynamics<false><<<dim3(h->NS / 64), dim3(384), 0, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, h->NS);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
@@ -339,6 +368,7 @@ int dexsim_init_state(dexsim_t h, void* stream) {
   HIP_TRY(hipMemsetAsync(h->api.episode_length, 0, sizeof(int64_t) * h->N, (hipStream_t)stream));
   HIP_TRY(hipMemsetAsync(h->api.reset_buf, 0, h->N, (hipStream_t)stream));
   HIP_TRY(hipMemsetAsync(h->api.rew_buf, 0, sizeof(float) * h->N, (hipStream_t)stream));
+  h->api.stamp = 1;
   k_init<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->NS, h->N);
   LAUNCH_CHECK();
   return launch_publish(h, 0, 0, stream);
@@ -347,7 +377,10 @@ int dexsim_init_state(dexsim_t h, void* stream) {
 int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, void* stream) {
   NEED_BOUND(h);
   if (!actions) return fail(DEXSIM_ERR_ARG, "Actions cannot be None");   // action_processor.py:296-297
-  k_actions<<<GRID(h)>>>(h->arena, h->api, h->d_params, actions, zero_targets, h->NS, h->N);
+  next_stamp(h);   // the action stage opens a control step
+  ApiPtrs api = h->api;
+  if (api.actions_copy == actions) api.actions_copy = nullptr;   // the caller passed the bound copy itself: nothing to copy
+  k_actions<<<GRID(h)>>>(h->arena, api, h->d_params, actions, zero_targets, h->NS, h->N);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }
@@ -359,7 +392,11 @@ static int physics_step(dexsim_t h, int gate_on_reset, int tail, void* stream, c
     const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
     const dim3 grid(h->NS / 64), block(448);
     if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, tail, h->NS, h->N);
-    else k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, actions, tail, h->NS, h->N);
+    else {
+      ApiPtrs api = h->api;
+      if (api.actions_copy == actions) api.actions_copy = nullptr;   // `act` is __restrict__: never alias it with the copy sink
+      k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, api, h->d_params, h->api.counters, actions, tail, h->NS, h->N);
+    }
     LAUNCH_CHECK();
     return DEXSIM_OK;
   }
@@ -401,6 +438,7 @@ int dexsim_step(dexsim_t h, const float* actions, void* stream) {
     // actions + physics + post-physics (+ phase 0 of the in-step reset) in one launch, then the device-gated extra
     // physics step with phase 1 of the reset and the step statistics: a control step is 2 launches
     if (!actions) return fail(DEXSIM_ERR_ARG, "Actions cannot be None");   // action_processor.py:296-297
+    next_stamp(h);
     h->last_actions = actions;
     const int slot = h->timing ? ((h->timing - 1) & 63) : -1;
     if (slot >= 0) HIP_TRY(hipEventRecord(h->tev[2 * slot], (hipStream_t)stream));
@@ -433,7 +471,8 @@ int dexsim_reset_idx(dexsim_t h, const int64_t* env_ids, int k, void* stream) {
 
 int dexsim_reset(dexsim_t h, void* stream) {
   NEED_BOUND(h);
-  k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters);
+  next_stamp(h);
+  k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters, h->api.stamp);
   LAUNCH_CHECK();
   int rc = dexsim_reset_idx(h, nullptr, h->N, stream);
   if (rc) return rc;
@@ -471,13 +510,14 @@ static int launch_stage(dexsim_t h, int stage, void* stream) {
       return physics_step(h, 0, 2, stream, h->last_actions);
     case DEXSIM_STAGE_POST: k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 0, 0, h->NS, h->N); break;
     case DEXSIM_STAGE_POST + 100: k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, 1, 0, h->NS, h->N); break;
-    case DEXSIM_STAGE_RESET:
-      k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 0, h->NS, h->N);
-      k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 0, 1, h->NS, h->N);
+    case DEXSIM_STAGE_RESET:   // both phases for the flagged envs, without the device-side gate and without physics
+      k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 3, 0, h->NS, h->N);
+      k_reset<<<GRID(h)>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, 0, 3, 1, h->NS, h->N);
       break;
-    case DEXSIM_STAGE_FINALIZE:
+    case DEXSIM_STAGE_FINALIZE:   // closes a staged control step and opens the next one
       k_finalize<<<1, 64, 0, (hipStream_t)stream>>>(h->api, h->d_params, h->N);
-      k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters);
+      next_stamp(h);
+      k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters, h->api.stamp);
       break;
     default: return fail(DEXSIM_ERR_ARG, "unknown stage");
   }
@@ -507,6 +547,14 @@ int dexsim_time_stage(dexsim_t h, int stage, int launches, void* stream, float* 
     total += ms;
   }
   *mean_us = (float)(total * 1000.0 / launches);
+  return DEXSIM_OK;
+}
+
+int dexsim_begin_step(dexsim_t h, void* stream) {
+  NEED_BOUND(h);
+  next_stamp(h);
+  k_begin_step<<<1, 64, 0, (hipStream_t)stream>>>(h->api.counters, h->api.stamp);
+  LAUNCH_CHECK();
   return DEXSIM_OK;
 }
 

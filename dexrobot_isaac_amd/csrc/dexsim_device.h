@@ -72,14 +72,20 @@ struct DevParams {
 };
 
 // counters block (ints): reduction scratch + device-side control flags
-#define CNT_ANY_RESET 0   /* set by the post kernel when some env must reset this step          */
+// CNT_ANY_RESET holds a STEP STAMP, not a boolean: the post block of control step `stamp` (a host-side counter, handed to
+// every kernel in ApiPtrs::stamp) stores `stamp` when some env must reset; gated launches run iff the word equals their
+// stamp.  Nothing ever clears the word, so no launch both clears and sets it (round 1 cleared it in block 0 of the very
+// launch whose other blocks set it: an unordered write/atomic pair on a control flag).
+#define CNT_ANY_RESET 0
 #define CNT_SUCC 1        /* [NUM_SUCC] */
 #define CNT_FAIL 2        /* [NUM_FAIL] */
 #define CNT_TERM_SUCCESS 8
 #define CNT_TERM_FAILURE 9
 #define CNT_TERM_TIMEOUT 10
 #define CNT_NUM_RESETS 11
-#define CNT_CONTACTS 12   /* sum of active contacts in the last solver invocation */
+#define CNT_CONTACTS 16   /* [2], by stamp parity: sum of active contacts of the control step's main physics step (last
+                             sub-step); word stamp&1 is accumulated and read by the step, the other word is cleared for the next */
+#define CNT_HAND_CONTACTS 18 /* [2], same scheme: the hand/box and hand/ground contacts among them */
 #define CNT_PHYS_STEPS 13
 #define CNT_CONSECUTIVE 14 /* persistent */
 #define CNT_RC_FIRST 15    /* persistent: RewardCalculator lazy prev-state init pending */

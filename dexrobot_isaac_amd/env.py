@@ -448,12 +448,27 @@ class DexHandEnv:
 
     # ------------------------------------------------------------------ lifecycle
     def _apply_pre_action_rule(self):
+        """The custom pre-action rule (rules.py:78-95).  The reference applies it between compute_observations and
+        concatenate_observations (step_processor.py:56-77), i.e. on the obs_dict of the terminal state, before termination,
+        rewards and the in-step resets.  Here the fused step has already run all of that with the identity default; nothing
+        in termination or rewards reads active_rule_targets, and obs_all still holds the PRE-reset observations, so the
+        rule is evaluated afterwards on the same inputs the reference gives it -- obs_dict of the terminal state and the
+        pre-reset active_prev_targets (the obs_dict entry, not the post-reset field) -- and its output is patched into
+        the field the next action stage reads, the obs_dict row and, when the key is a policy observation, into the
+        obs_buf / rollout-sink columns."""
         rule = self.action_processor._pre_action_rule
-        if rule is not None:   # identity default already written by the post kernel
-            out = rule(self.action_processor.active_prev_targets.clone(), {"obs_dict": self.obs_dict, "env": self})
-            self._core.field("active_rule_targets").copy_(out.t())
-            off, dim = obs_key_offsets()["active_rule_targets"]
-            self._core.field("obs_all")[off:off + dim].copy_(out.t())
+        if rule is None:       # identity default already written by the post kernel
+            return
+        out = rule(self.obs_dict["active_prev_targets"].clone(), {"obs_dict": self.obs_dict, "env": self})
+        self._core.field("active_rule_targets").copy_(out.t())
+        off, dim = obs_key_offsets()["active_rule_targets"]
+        self._core.field("obs_all")[off:off + dim].copy_(out.t())
+        sl = self.observation_encoder.component_slice_indices.get("active_rule_targets")
+        if sl is not None:
+            self.obs_buf[:, sl[0]:sl[1]] = out
+            sink = getattr(self._core, "_sink_obs", None)
+            if sink is not None:
+                sink[:, sl[0]:sl[1]] = out
 
     def step(self, actions):
         """obs (N,O) f32, rew (N,) f32, done (N,) bool, extras -- views of env-owned buffers."""
@@ -488,7 +503,17 @@ class DexHandEnv:
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def reset(self):
-        self._core.reset()
+        if self.action_processor._pre_action_rule is None:
+            self._core.reset()
+            return self.obs_buf
+        # with a custom pre-action rule the reference's sequence is spelled out, because the rule runs inside BOTH
+        # observation passes of reset() (dexhand_base.py:805-838: compute_observations, then post_physics_step)
+        core = self._core
+        core.begin_step()
+        core.reset_idx(torch.arange(self.num_envs, device=self.device))
+        core.post_physics(True)
+        self._apply_pre_action_rule()
+        core.post_physics(False)
         self._apply_pre_action_rule()
         return self.obs_buf
 
@@ -498,7 +523,10 @@ class DexHandEnv:
         self._core.reset_idx(env_ids)
 
     def pre_physics_step(self, actions):
-        self.actions = actions.clone()
+        if self._actions_copy_bound:
+            self.actions.copy_(actions)      # keep the tensor the device-side action copy is bound to
+        else:
+            self.actions = actions.clone()   # dexhand_base.py:851
         self._core.process_actions(self.actions)
 
     def post_physics_step(self):

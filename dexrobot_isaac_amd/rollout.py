@@ -3,11 +3,20 @@ into the PPO buffer (BASELINE.json north_star).  One process per
 sharded by rank with no exchange inside step(); `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo"
 is used by the CPU tests.
 
-xGMI is point-to-point (7 links/GPU), so the gather is issued as ONE all_gather_into_tensor per tensor per
-rollout (41.7 MB/rank at N=4096, T=16, O=158) rather than per step: few, large messages.  The buffer is
-double-buffered: `gather_async()` enqueues the collectives (RCCL runs them on its own HIP stream) and the
-env keeps stepping into the other slot, so the ~1-3 ms of xGMI traffic overlaps the next rollout's ~3.5 ms of
-simulation instead of serialising with it.
+xGMI is point-to-point (7 links/GPU), so the gather is issued as ONE collective per tensor per rollout
+(41.7 MB/rank at N=4096, T=16, O=158) rather than per step: few, large messages.  Two modes:
+
+  mode="learner" (default): `gather` to one learner rank (north_star: "gather into the PPO buffer").  Every other rank
+      only SENDS its 41.7 MB over its direct xGMI link to the learner; the learner receives (R-1) x 41.7 MB spread over
+      its 7 links.  This is 1/R of the receive traffic of an all-gather on the non-learner ranks.
+  mode="all": `all_gather_into_tensor` -- every rank ends up with the full batch (data-parallel learners that each
+      train on the whole buffer).  R x the receive traffic; at ~0.1 ms per control step a 16-step rollout is only
+      ~1.6 ms of simulation, which an 8-rank all-gather (8 x 41.7 MB into every GPU) no longer hides.
+
+The buffer is double-buffered: `gather_async()` enqueues the collectives (RCCL runs them on its own HIP stream) and
+the env keeps stepping into the other slot, so the xGMI traffic overlaps the next rollout's simulation instead of
+serialising with it; bench.py prints the simulation ms per rollout next to the collective ms so that the overlap (or
+its absence) is visible.
 """
 import torch
 import torch.distributed as dist
@@ -23,7 +32,10 @@ class _Slot:
 
 
 class RolloutBuffer:
-    def __init__(self, horizon, num_envs, num_obs, device, slots=2):
+    def __init__(self, horizon, num_envs, num_obs, device, slots=2, mode="learner", learner_rank=0):
+        if mode not in ("learner", "all"):
+            raise ValueError("mode must be 'learner' (gather to one rank) or 'all' (all-gather)")
+        self.mode, self.learner_rank = mode, int(learner_rank)
         self.T, self.N, self.O = int(horizon), int(num_envs), int(num_obs)
         self.device = torch.device(device)
         self.slots = [_Slot(self.T, self.N, self.O, self.device) for _ in range(max(1, int(slots)))]
@@ -83,9 +95,14 @@ class RolloutBuffer:
             w.wait()                           # stream-level wait on the device; does not block the host for nccl
         slot.work = []
 
+    def _is_receiver(self):
+        return self.mode == "all" or dist.get_rank() == self.learner_rank
+
     def _views(self, slot):
         if not self._distributed():
             return slot.obs, slot.rew, slot.done
+        if not self._is_receiver():
+            return None                        # mode "learner": only the learner rank holds the full batch
         R, T, N, O = dist.get_world_size(), self.T, self.N, self.O
         go, gr, gd = slot.gathered
         return (go.view(R, T, N, O).permute(1, 0, 2, 3).reshape(T, R * N, O),
@@ -93,18 +110,23 @@ class RolloutBuffer:
 
     def gather_async(self):
         """Enqueue the gather of the slot just filled and switch to the next slot.  Returns a handle; call
-        `handle()` to obtain (obs (T, R*N, O), rew (T, R*N), done (T, R*N)) -- env index = rank*N + local."""
+        `handle()` to obtain (obs (T, R*N, O), rew (T, R*N), done (T, R*N)) -- env index = rank*N + local -- on the
+        receiving rank(s); on the other ranks of mode "learner" the handle returns None once their sends are done."""
         slot = self.slots[self.cur]
         if self._distributed():
             R = dist.get_world_size()
-            if slot.gathered is None:
+            if slot.gathered is None and self._is_receiver():
                 # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept)
                 slot.gathered = (torch.empty(R * self.T, self.N, self.O, device=self.device),
                                  torch.empty(R * self.T, self.N, device=self.device),
                                  torch.empty(R * self.T, self.N, dtype=torch.uint8, device=self.device))
-            slot.work = [dist.all_gather_into_tensor(slot.gathered[0], slot.obs, async_op=True),
-                         dist.all_gather_into_tensor(slot.gathered[1], slot.rew, async_op=True),
-                         dist.all_gather_into_tensor(slot.gathered[2], slot.done, async_op=True)]
+            src = (slot.obs, slot.rew, slot.done)
+            if self.mode == "all":
+                slot.work = [dist.all_gather_into_tensor(g, t, async_op=True) for g, t in zip(slot.gathered, src)]
+            else:
+                recv = dist.get_rank() == self.learner_rank
+                slot.work = [dist.gather(t, list(slot.gathered[i].chunk(R, dim=0)) if recv else None,
+                                         dst=self.learner_rank, async_op=True) for i, t in enumerate(src)]
         self.cur = (self.cur + 1) % len(self.slots)
         self.t = 0
 

@@ -133,7 +133,8 @@ enum {
 #define DEXSIM_STAT_CONSECUTIVE_SUCCESSES 15
 #define DEXSIM_STAT_NUM_RESETS  16 /* envs reset in this control step                          */
 #define DEXSIM_STAT_PHYSICS_STEPS 17 /* physics steps executed in this control step (1 or 2)   */
-#define DEXSIM_STAT_MEAN_CONTACTS 18 /* mean active contacts/env in the last solver invocation */
+#define DEXSIM_STAT_MEAN_CONTACTS 18 /* mean active contacts/env in the last sub-step of the step's main physics step */
+#define DEXSIM_STAT_MEAN_HAND_CONTACTS 19 /* ... of which hand/box and hand/ground (the rest is box/ground)            */
 #define DEXSIM_STAT_WORDS 64
 
 /* number of hand bodies published in rigid_body_states: 7 base-chain + 30 finger bodies */
@@ -296,6 +297,12 @@ int dexsim_init_state(dexsim_t h, void* stream);
  * actions: (N, num_actions) device.  zero_targets != 0 reproduces the pre-finalize_setup branch
  * (:305-318). */
 int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, void* stream);
+
+/* Opens a control step whose action stage ran on the host (custom post-action filters / coupling rule,
+ * action_processor.py:698-720, write targets and active_prev_targets into the arena directly): what
+ * dexsim_process_actions does for the device-side step bookkeeping (new stamp of the device-side reset gate, contact
+ * statistics words), without touching targets. */
+int dexsim_begin_step(dexsim_t h, void* stream);
 
 /* PhysicsManager.step_physics = gym.simulate + fetch_results + 4 refreshes
  * (physics_manager.py:73-119): one sim.dt = `substeps` sub-steps for every env, then publish

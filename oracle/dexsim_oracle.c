@@ -1076,9 +1076,13 @@ void orc_physics_step(void* h) {
   PAR_FOR
   for (int i = 0; i < o->n; i++) physics_step_env(o, &o->env[i]);
   o->stats[DEXSIM_STAT_PHYSICS_STEPS] += 1;
-  double kc = 0;
-  for (int i = 0; i < o->n; i++) kc += o->env[i].ncontact;
+  double kc = 0, kh = 0;
+  for (int i = 0; i < o->n; i++) {
+    kc += o->env[i].ncontact;
+    for (int k = 0; k < o->env[i].ncontact; k++) kh += o->env[i].contact[k].type != 2;
+  }
   o->stats[DEXSIM_STAT_MEAN_CONTACTS] = (float)(kc / o->n);
+  o->stats[DEXSIM_STAT_MEAN_HAND_CONTACTS] = (float)(kh / o->n);
 }
 
 /* single sub-step / publish, for teacher-forced parity tests */
@@ -1149,7 +1153,10 @@ void orc_step(void* h, const float* actions) { /* DexHandBase.step (dexhand_base
   o->stats[DEXSIM_STAT_PHYSICS_STEPS] = 0;
   orc_process_actions(h, actions, 0);
   orc_physics_step(h);
+  /* the contact statistics of a control step are those of its main physics step (not of the conditional extra one) */
+  const float kc = o->stats[DEXSIM_STAT_MEAN_CONTACTS], kh = o->stats[DEXSIM_STAT_MEAN_HAND_CONTACTS];
   orc_post_physics(h, 0);
+  o->stats[DEXSIM_STAT_MEAN_CONTACTS] = kc; o->stats[DEXSIM_STAT_MEAN_HAND_CONTACTS] = kh;
 }
 
 void orc_reset_idx(void* h, const int64_t* ids, int k) { /* DexHandBase.reset_idx (dexhand_base.py:743-803) */

@@ -82,6 +82,9 @@ class OracleCore:
         self.orc.init_state()
         self._sync()
 
+    def begin_step(self):
+        pass                                   # device-side step bookkeeping only exists on the HIP path
+
     def process_actions(self, actions, zero_targets=False):
         self.orc.process_actions(actions.detach().cpu().numpy(), zero_targets)
         self._sync()

@@ -6,7 +6,6 @@ import torch
 from dexrobot_isaac_amd import _abi
 from dexrobot_isaac_amd.core import DexSimCore
 
-CNT_ANY_RESET = 0
 
 
 class HipBackend:
@@ -59,8 +58,7 @@ class HipBackend:
         self._posted = True
 
     def reset_flagged_no_physics(self):
-        self.core.counters[CNT_ANY_RESET] = 1
-        self.core.run_stage(_abi.STAGE["RESET"])
+        self.core.run_stage(_abi.STAGE["RESET"])        # flagged envs, no device-side gate, no physics
 
     def substep(self, last=True):
         if self.fused:

@@ -124,3 +124,40 @@ def test_reset_idx_and_hooks():
     env.action_processor._enabled_post_action_filters = ["velocity_clamp", "position_clamp"]
     with pytest.raises(RuntimeError, match="None"):
         env.step(None)
+
+
+def test_pre_action_rule_follows_the_reference_ordering():
+    """step_processor.py:56-77: the custom pre-action rule runs between compute_observations and
+    concatenate_observations, on the terminal obs_dict and the PRE-reset active_prev_targets, and its output is what the
+    policy sees when active_rule_targets is a policy observation key; reset() runs it in both observation passes
+    (dexhand_base.py:805-838)."""
+    cfg = default_cfg("BlindGrasping")
+    cfg["env"]["episodeLength"] = 4                              # time-outs -> in-step resets at step 3
+    cfg["task"]["policy_observation_keys"] = list(cfg["task"]["policy_observation_keys"]) + ["active_rule_targets"]
+    env = make_env("BlindGrasping", 5, "cpu", "cpu", 0, cfg=cfg, _core_factory=OracleCore)
+    assert env.num_observations == 158 + 18
+    seen = []
+
+    def rule(prev, state):
+        seen.append((prev.clone(), state["obs_dict"]["active_prev_targets"].clone(), state["obs_dict"]["episode_time"].clone()))
+        out = prev.clone()
+        out[:, 3] = 0.25 + 0.01 * len(seen)
+        return out
+
+    env.action_processor.set_pre_action_rule(rule)
+    env.reset()
+    assert len(seen) == 2                                        # both observation passes of reset()
+    sl = env.observation_encoder.component_slice_indices["active_rule_targets"]
+    assert torch.allclose(env.obs_buf[:, sl[0] + 3], torch.full((5,), 0.27))
+    done_seen = False
+    for t in range(5):
+        obs, rew, done, _ = env.step(0.5 * torch.ones(5, 18))
+        prev, ob_prev, _ = seen[-1]
+        assert torch.equal(prev, ob_prev)                        # the rule got the pre-reset targets (the obs_dict entry)
+        assert torch.allclose(obs[:, sl[0] + 3], torch.full((5,), 0.25 + 0.01 * len(seen)))   # ... and the policy sees its output
+        assert torch.allclose(env.action_processor.active_rule_targets[:, 3], obs[:, sl[0] + 3])
+        if bool(done.any()):
+            done_seen = True
+            # after an in-step reset the field holds the post-reset targets, the rule was still given the terminal ones
+            assert not torch.equal(env.action_processor.active_prev_targets, ob_prev)
+    assert done_seen

@@ -489,3 +489,144 @@ def test_step_sink_writes_rollout_rows():
     core.step(a)
     torch.cuda.synchronize()
     assert torch.equal(rb.slots[0].obs[7], before)
+
+
+def test_reset_gate_when_only_the_last_workgroup_resets():
+    """The device-side reset gate is a step stamp (dexsim_device.h, CNT_ANY_RESET): nothing clears it, so a reset raised
+    by the LAST workgroup of a grid that is larger than one residency wave (257 workgroups + a padded one) must still
+    open the gated launch for every workgroup -- extra physics step for all envs, phase 1 of the reset for the flagged
+    ones -- and the gate must close again in the following steps.  Checked against the oracle."""
+    import torch
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 64 * 257 + 5
+    sc, model = _mk("BlindGrasping", n, **{"env.episodeLength": 40})
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms, threads=8), HipBackend(sc, ms)
+    obs_o, obs_h = o.reset(), hb.reset()
+    es = np.zeros((1, n))
+    es[0, 64 * 257:] = 37                                    # the five envs of the last (padded) workgroup time out at step 1
+    o.set("episode_step", es)
+    hb.set("episode_step", es)
+    rng = np.random.default_rng(11)
+    for t in range(3):
+        a = (2 * rng.random((n, 18)) - 1).astype(np.float32)
+        oo, ro, do = o.step(a)
+        oh, rh, dh = hb.step(a)
+        st_h, st_o = hb.stats(), o.stats()
+        assert st_h[16] == st_o[16] == (5 if t == 1 else 0)                  # resets in this step
+        assert st_h[17] == (2 if t == 1 else 1)                              # physics steps in this step
+        assert (do == dh.astype(bool)).all() and do.sum() == (5 if t == 1 else 0)
+        np.testing.assert_allclose(oh, oo, atol=2e-3)
+        if t == 1:
+            # phase 1 ran for the flagged envs (observer state zeroed after the extra physics step) ...
+            assert (hb.get("prev_actions")[:, 64 * 257:] == 0).all() and (hb.get("prev_dof_pos")[:, 64 * 257:] == 0).all()
+            assert (hb.get("reset_count")[0, 64 * 257:] == 2).all() and (hb.get("reset_count")[0, :64 * 257] == 1).all()
+            # ... and the extra physics step ran for ALL envs, first workgroup included
+        np.testing.assert_allclose(hb.get("q")[:, :64], o.get("q")[:, :64], atol=5e-4)
+        np.testing.assert_allclose(hb.get("q")[:, -5:], o.get("q")[:, -5:], atol=5e-4)
+        assert abs(st_h[18] - st_o[18]) < 0.01 and abs(st_h[19] - st_o[19]) < 0.01   # mean contacts (total, hand) of the main step
+
+
+def test_config2_base_task_position_1024_free_running():
+    """BASELINE configs[1] at its stated shape: BaseTask, num_envs=1024, position control, no object (articulated
+    forward dynamics only), 30 free-running control steps with random actions against the oracle.  No contacts, so the
+    trajectories do not bifurcate: every env is compared, max error over all envs and steps."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 1024
+    sc, model = _mk("BaseTask", n, **{"task.controlMode": "position"})
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms, threads=8), HipBackend(sc, ms)
+    np.testing.assert_allclose(hb.reset(), o.reset(), atol=2e-5)
+    rng = np.random.default_rng(21)
+    worst_obs = worst_rew = 0.0
+    for t in range(30):
+        a = (2 * rng.random((n, 18)) - 1).astype(np.float32)
+        oo, ro, do = o.step(a)
+        oh, rh, dh = hb.step(a)
+        assert (do == dh.astype(bool)).all()
+        worst_obs = max(worst_obs, float(np.abs(oh - oo).max()))
+        worst_rew = max(worst_rew, float(np.abs(rh - ro).max()))
+    # velocities are finite differences of q over control_dt = 0.01 s (x100), q itself agrees to ~1e-5
+    assert worst_obs < 5e-3 and worst_rew < 1e-3, (worst_obs, worst_rew)
+    np.testing.assert_allclose(hb.get("q"), o.get("q"), atol=5e-5)
+    assert o.get("ncontact").max() == 0 and hb.get("ncontact").max() == 0
+
+
+def test_config5_dr_8192_with_reset_churn():
+    """BASELINE configs[4] at its stated shape: num_envs=8192, per-env box mass / friction randomisation, episode clocks
+    staggered so that some env resets in every control step (reset_idx churn: the device-gated second physics step runs
+    every step), 30 control steps with random actions against the oracle on the same device/host Philox streams.  The bar
+    is the free-running one: exact integer bookkeeping for envs that did not bifurcate, statistical for trajectories."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 8192
+    cfg = default_cfg("BlindGrasping")
+    cfg["env"]["numEnvs"] = n
+    dr = {"mass": (0.05, 0.2), "friction": (0.5, 1.5), "seed": 4242}
+    sc, model = build_sim_config(cfg, dr=dr)
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms, threads=16), HipBackend(sc, ms)
+    np.testing.assert_allclose(hb.get("box_mass"), o.get("box_mass"), rtol=5e-7)
+    np.testing.assert_allclose(hb.get("box_mu"), o.get("box_mu"), rtol=5e-7)
+    np.testing.assert_allclose(hb.reset(), o.reset(), atol=2e-4)
+    rng = np.random.default_rng(31)
+    k = rng.integers(170, 200, (1, n))                      # stage-1 clocks: every env fails the pre-grasp check within 30 steps
+    for b in (o, hb):
+        b.set("episode_step", k)
+        b.set("time_in_stage", k * float(sc.control_dt))
+    errs, mism, resets = [], 0, 0
+    for t in range(30):
+        a = (2 * rng.random((n, 18)) - 1).astype(np.float32)
+        oo, ro, do = o.step(a)
+        oh, rh, dh = hb.step(a)
+        errs.append(np.abs(oh - oo).max(axis=1))
+        mism += int((do != dh.astype(bool)).sum())
+        assert abs(hb.stats()[16] - o.stats()[16]) <= 2     # resets this step
+        assert hb.stats()[17] == (2 if do.any() else 1)
+        resets += int(do.sum())
+    errs = np.stack(errs)
+    assert np.median(errs) < 1e-4 and np.percentile(errs, 99) < 5e-3, (np.median(errs), np.percentile(errs, 99))
+    assert mism <= 8 and resets >= n                         # every env was reset once; <0.01 % done-flag bifurcations
+    assert (np.abs(hb.get("reset_count") - o.get("reset_count")).sum()) <= 8
+    assert np.isfinite(hb.obs_buf()).all()
+
+
+def test_hip_error_is_a_small_multiple_of_fp32_roundoff():
+    """Derives the physics tolerance instead of asserting it: the same teacher-forced sub-step on the fp64 oracle, the
+    fp32 oracle (dense Cholesky) and the HIP kernels (block/Schur factorisation, fp32).  For every field the HIP error
+    against fp64 must stay within a small multiple c of the fp32 oracle's own error against fp64, at the 99.9th percentile
+    and at the maximum, over the envs whose contact sets agree in all three (a contact appearing or not is a discontinuity,
+    not roundoff)."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 512
+    sc, model = _mk("BlindGrasping", n)
+    ms = model.to_struct()
+    o64, o32, hb = Oracle(sc, ms, f64=True), Oracle(sc, ms), HipBackend(sc, ms)
+    rng = np.random.default_rng(41)
+    report = {}
+    for trial, near in enumerate((True, False, True)):
+        st = _random_state(rng, model, n, near_box=near)
+        for b in (o64, o32, hb):
+            for k, v in st.items():
+                b.set(k, np.asarray(v, dtype=np.float32))    # identical fp32-representable state everywhere
+        for b in (o64, o32, hb):
+            b.substep(last=True)
+        same = (o64.get("ncontact")[0] == o32.get("ncontact")[0]) & (o64.get("ncontact")[0] == hb.get("ncontact")[0])
+        assert same.mean() > 0.97
+        for f in ("q", "qd", "box_pos", "box_lin", "box_ang", "cforce"):
+            ref = o64.get(f)[:, same]
+            e32 = np.abs(o32.get(f)[:, same] - ref).ravel()
+            eh = np.abs(hb.get(f)[:, same] - ref).ravel()
+            r = report.setdefault(f, [0.0, 0.0, 0.0, 0.0])
+            r[0] = max(r[0], np.percentile(e32, 99.9)); r[1] = max(r[1], np.percentile(eh, 99.9))
+            r[2] = max(r[2], e32.max()); r[3] = max(r[3], eh.max())
+    print("\nfield: p99.9 |f32-f64|, p99.9 |HIP-f64|, max |f32-f64|, max |HIP-f64|")
+    for f, r in report.items():
+        print(f"  {f:8s} {r[0]:.3e} {r[1]:.3e} {r[2]:.3e} {r[3]:.3e}")
+    c = 8.0
+    for f, r in report.items():
+        assert r[1] <= c * r[0] + 1e-7, (f, r)
+        assert r[3] <= c * r[2] + 1e-6, (f, r)
