@@ -335,8 +335,8 @@ static size_t solve_lds_bytes(int kstage) { return (size_t)SOLVE_LDS_WORDS(kstag
 static int launch_solve(dexsim_t h, int gate, int last, void* stream) {
   const int ks = solve_kstage(h);
   const size_t lds = solve_lds_bytes(ks);
-  if (gate) k_solve<true><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, last, ks, h->NS);
-  else k_solve<false><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, last, ks, h->NS);
+  if (gate) k_solve<true><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, last, ks, h->NS, h->N);
+  else k_solve<false><<<dim3(h->NS / 64), dim3(64), lds, (hipStream_t)stream>>>(h->arena, h->d_params, h->api.counters, h->api.stamp, last, ks, h->NS, h->N);
   LAUNCH_CHECK();
   return DEXSIM_OK;
 }

@@ -266,6 +266,8 @@ class FakeParent:
         """'gym.simulate': overwrite the engine tensors with the next scripted L1 state."""
         s = self.l1[self.l1_cursor]
         self.l1_cursor += 1
+        if getattr(self, "l1_hook", None) is not None:
+            self.l1_hook(self, s)            # may adapt the scripted state in place (recorded as modified)
         self.dof_state[..., 0] = torch.tensor(s["q"])
         self.dof_state[..., 1] = torch.tensor(s["qd"])
         self.rigid_body_states[:] = torch.tensor(s["rbs"])
@@ -277,6 +279,10 @@ class FakeParent:
     def reset_idx(self, env_ids):
         if len(env_ids) == 0:
             return
+        # for the per-step snapshots: the obs_dict the step's obs_buf was built from.  Several obs_dict entries are VIEWS of
+        # the engine tensors (dof_pos, root / rigid-body state), so after the reset's physics step they show the post-reset
+        # state of every env while obs_buf keeps the terminal observation.
+        self.obs_dict_pre_reset = {k: v.clone() for k, v in self.obs_dict.items()} if self.obs_dict else None
         self.termination_manager.reset_tracking(env_ids)
         self.reset_manager.reset_idx(env_ids)
         self.observation_encoder.reset_observer_state(env_ids)
@@ -308,7 +314,7 @@ def quat_norm(q):
     return q / np.linalg.norm(q, axis=-1, keepdims=True)
 
 
-def make_l1_script(rng, model, N, T, has_box, profile):
+def make_l1_script(rng, model, N, T, has_box, profile, extra_states=0):
     """Synthetic sim-state sequence: 2 states per control step (main physics step, optional reset step)."""
     B = len(model.body_names) + (1 if has_box else 0)
     hb, tips, pads = model.hand_local_rigid_body_index, model.fingertip_local_indices, model.fingerpad_local_indices
@@ -322,7 +328,7 @@ def make_l1_script(rng, model, N, T, has_box, profile):
     box0[:, 2] = 0.0255
     box0[:, 6] = 1.0
     group = np.arange(N) % 6
-    for t in range(2 * T + 4):
+    for t in range(2 * T + 4 + extra_states):
         k = t // 2
         q = np.clip(q + rng.normal(0, 0.01, q.shape).astype(np.float32), lo - 0.01, hi + 0.01).astype(np.float32)
         qd = rng.normal(0, 0.5, (N, 26)).astype(np.float32)
@@ -378,6 +384,37 @@ def make_l1_script(rng, model, N, T, has_box, profile):
             g5 = group == 5
             if (k // 3) % 2 == 0:
                 cf[np.ix_(g5, [c5[3]])] = np.array([0.3, 0.0, 0.2], dtype=np.float32)
+        elif profile == "long":
+            # default-length FSM (stage 1 = 4 s = 200 control steps, stage 2 <= 3 s, success after 2 s of lifted grasp):
+            # group 1 keeps a good pre-grasp pose, touches from script state 205 (stage 3 by contact duration at ~230), lifts at
+            # state 232 and holds -> grasp_lift_success; group 2 has policy-observable contact without box force ->
+            # stage2_contact_failed; the other groups fail the pre-grasp check at control step ~199
+            g1 = group == 1
+            for f in range(5):
+                off = np.array([0.02 * (f - 2), 0.0, 0.0], dtype=np.float32)
+                rbs[g1, pads[f], :3] = box0[g1, :3] + off + rng.normal(0, 0.002, (g1.sum(), 3))
+                rbs[g1, tips[f], :3] = rbs[g1, pads[f], :3] + np.array([0, 0, 0.03], dtype=np.float32)
+            box[g1, 7:10] = rng.normal(0, 0.0005, (g1.sum(), 3))
+            if t >= 205:
+                for f in (0, 1, 2):
+                    cf[np.ix_(g1, [c5[f]])] = np.array([0.5, 0.2, 0.3], dtype=np.float32)
+                cf[g1, B - 1, :] = np.array([0.6, 0.1, 1.2], dtype=np.float32)
+            if t >= 232:
+                box[g1, 2] = 0.25
+                for f in range(5):
+                    off = np.array([0.02 * (f - 2), 0.0, 0.0], dtype=np.float32)
+                    rbs[g1, pads[f], :3] = box[g1, :3] + off
+                    rbs[g1, tips[f], :3] = rbs[g1, pads[f], :3] + np.array([0, 0, 0.03], dtype=np.float32)
+            g2 = group == 2
+            for f in range(5):
+                off = np.array([0.02 * (f - 2), 0.0, 0.0], dtype=np.float32)
+                rbs[g2, pads[f], :3] = box0[g2, :3] + off + rng.normal(0, 0.002, (g2.sum(), 3))
+                rbs[g2, tips[f], :3] = rbs[g2, pads[f], :3] + np.array([0, 0, 0.03], dtype=np.float32)
+            box[g2, 7:10] = rng.normal(0, 0.0005, (g2.sum(), 3))
+            if t >= 205:
+                for f in (0, 1):
+                    cf[np.ix_(g2, [c5[f]])] = np.array([0.0, 0.4, 0.0], dtype=np.float32)
+                cf[g2, B - 1, :] = 0.0
         else:
             if k % 7 in (2, 3, 4):
                 cf[::2, c5[1], :] = rng.normal(0, 1.0, (len(range(0, N, 2)), 3))
@@ -414,15 +451,17 @@ def scenario_cfg(name):
     from dexrobot_isaac_amd.config import default_cfg
     if name == "blind_default":
         cfg, over = default_cfg("BlindGrasping"), {}
-    elif name == "blind_fast":
+    elif name == "blind_long":
+        cfg, over = default_cfg("BlindGrasping"), {}
+    elif name in ("blind_fast", "blind_wide"):
         cfg = default_cfg("BlindGrasping")
         over = {"env.episodeLength": 24, "task.stage1_duration": 0.1, "task.stage2_duration": 0.2,
                 "task.stage_evaluation.stage2_contact_success_threshold": 0.06,
                 "task.contact_duration_threshold": 0.1}
     elif name == "base_default":
         cfg, over = default_cfg("BaseTask"), {"env.episodeLength": 20}
-    elif name == "base_position":
-        cfg, over = default_cfg("BaseTask"), {"task.controlMode": "position", "env.episodeLength": 50}
+    elif name in ("base_position", "base_wide"):
+        cfg, over = default_cfg("BaseTask"), {"task.controlMode": "position", "env.episodeLength": 50 if name == "base_position" else 9}
     else:
         raise KeyError(name)
     for k, v in over.items():
@@ -434,15 +473,20 @@ def scenario_cfg(name):
     return cfg, over
 
 
-def run_scenario(name, N, T, seed):
+def run_scenario(name, N, T, seed, events=None, snap_steps=()):
+    """events: {step: [env ids]} -- an explicit env.reset_idx(ids) call (dexhand_base.py:743-803) BEFORE that step;
+    snap_steps: steps after which every obs_dict key and every reward component is recorded."""
+    from dexrobot_isaac_amd.config import OBS_KEYS
     from dexrobot_isaac_amd.hand_model import HandModel
+    events = events or {}
     cfg, over = scenario_cfg(name)
     cfg["env"]["numEnvs"] = N
     task_name = cfg["task"]["name"]
     has_box = task_name == "BlindGrasping"
     model = HandModel()
     rng = np.random.default_rng(seed)
-    script = make_l1_script(rng, model, N, T, has_box, "fast" if name == "blind_fast" else "default")
+    profile = {"blind_fast": "fast", "blind_wide": "fast", "blind_long": "long"}.get(name, "default")
+    script = make_l1_script(rng, model, N, T, has_box, profile, extra_states=len(events))
     torch.manual_seed(cfg["train"]["seed"])
     env = FakeParent(copy.deepcopy(cfg), model, task_name, script)
 
@@ -455,10 +499,35 @@ def run_scenario(name, N, T, seed):
         draws.append(out.clone())
         return out
 
+    if profile == "long":
+        # the scripted box (and the pads / tips placed relative to it) follows the position the reference's own reset drew,
+        # so that the pre-grasp drift check (box vs initial_box_positions, 1 cm) can pass and stages 2 / 3 are reached
+        pads_tips = model.fingerpad_local_indices + model.fingertip_local_indices
+
+        def follow_box(env_, st):
+            ib = env_.task.initial_box_positions.numpy()
+            d = (ib[:, :2] - st["box"][:, :2]).astype(np.float32)
+            st["box"][:, :2] += d
+            for b in pads_tips:
+                st["rbs"][:, b, :2] += d
+            st["rbs"][:, -1, :] = st["box"]
+        env.l1_hook = follow_box
+
     torch.rand = rec_rand
     rec = {k: [] for k in ("actions", "obs", "rew", "done", "targets", "active_prev_targets", "episode_step",
                            "reset_samples", "rew_total", "task_state", "stats")}
     l1_main, l1_reset, reset_l1_used = [], [], []
+    ev = {k: [] for k in ("step", "ids", "samples", "l1", "targets", "active_prev_targets", "episode_step", "task_state",
+                          "prev_actions_obs")}
+    snaps = {"step": [], "oa": [], "rc": [], "rc_names": None}
+    live_view_keys = set()
+
+    def task_state_now():
+        ts = env.observation_encoder.task_states
+        return np.stack([ts["current_stage"].numpy().astype(np.float32), ts["time_in_stage"].numpy(),
+                         ts["stage_contact_duration"].numpy(), ts["success_duration_steps"].numpy().astype(np.float32),
+                         ts["just_transitioned_to_stage2"].numpy().astype(np.float32),
+                         ts["just_transitioned_to_stage3"].numpy().astype(np.float32)])
 
     def collect_samples(env_ids_mask):
         """reshape the 6 rand calls of one reset_task_state into (N, 29) rows"""
@@ -481,8 +550,26 @@ def run_scenario(name, N, T, seed):
         extra_in_reset = env.l1_cursor - c0 - 1
         agen = np.random.default_rng(seed + 1)
         for t in range(T):
+            if t in events:                                  # explicit reset_idx(ids) between two steps
+                ids = np.asarray(events[t], dtype=np.int64)
+                c = env.l1_cursor
+                env.reset_idx(torch.as_tensor(ids))
+                assert env.l1_cursor == c + 1                # ResetManager.reset_idx ran its physics step
+                mask = np.zeros(N, dtype=bool)
+                mask[ids] = True
+                ev["step"].append(t)
+                ev["ids"].append(np.pad(ids, (0, N - len(ids)), constant_values=-1))
+                ev["samples"].append(collect_samples(mask))
+                ev["l1"].append(pack_l1(script[c], model, has_box))
+                ev["targets"].append(env.action_processor.full_dof_targets.numpy().copy())
+                ev["active_prev_targets"].append(env.action_processor.active_prev_targets.numpy().copy())
+                ev["episode_step"].append(env.episode_step_count.numpy().copy())
+                ev["prev_actions_obs"].append(env.observation_encoder.prev_actions.numpy().copy())
+                if has_box:
+                    ev["task_state"].append(task_state_now())
             a = torch.tensor(2.0 * agen.random((N, env.num_actions), dtype=np.float32) - 1.0)
             c = env.l1_cursor
+            env.obs_dict_pre_reset = None
             obs, rew, done, info = env.step(a)
             used = env.l1_cursor - c
             rec["actions"].append(a.numpy().copy())
@@ -505,6 +592,13 @@ def run_scenario(name, N, T, seed):
                                                    ts["success_duration_steps"].numpy().astype(np.float32),
                                                    ts["just_transitioned_to_stage2"].numpy().astype(np.float32),
                                                    ts["just_transitioned_to_stage3"].numpy().astype(np.float32)]))
+            if t in snap_steps:
+                od_now = env.obs_dict_pre_reset if env.obs_dict_pre_reset is not None else env.obs_dict
+                if env.obs_dict_pre_reset is not None:
+                    live_view_keys.update(k for k in od_now if not torch.equal(od_now[k], env.obs_dict[k]))
+                snaps["step"].append(t)
+                snaps["oa"].append(np.concatenate([od_now[k].reshape(N, -1).numpy() for k, _ in OBS_KEYS if k in od_now], axis=1))
+                snaps["rc"].append({k: v.numpy().copy() for k, v in info["reward_components"].items()})
             st = np.zeros(8, dtype=np.float32)
             st[0] = float(info["success_rate"])
             st[1] = float(info["failure_rate"])
@@ -520,10 +614,41 @@ def run_scenario(name, N, T, seed):
     for k, v in rec.items():
         if v:
             out[k] = np.stack(v)
+    if ev["step"]:
+        out["ev_step"] = np.array(ev["step"])
+        for k in ("ids", "samples", "targets", "active_prev_targets", "episode_step", "prev_actions_obs"):
+            out[f"ev_{k}"] = np.stack(ev[k])
+        if has_box:
+            out["ev_task_state"] = np.stack(ev["task_state"])
+        for f in ev["l1"][0]:
+            out[f"ev_l1_{f}"] = np.stack([s_[f] for s_ in ev["l1"]])
+    if snaps["step"]:
+        out["snap_step"] = np.array(snaps["step"])
+        out["snap_obs_all"] = np.stack(snaps["oa"])           # every obs_dict key, OBS_KEYS order
+        out["snap_obs_keys"] = json.dumps([k for k, _ in OBS_KEYS if k in env.obs_dict])
+        # keys whose obs_dict entry aliases an engine tensor in the reference (differs from the terminal observation after a
+        # step with resets); recorded for INTEGRATION.md, not replayed
+        out["snap_live_view_keys"] = json.dumps(sorted(live_view_keys))
+        # the reference's dict does not carry every key at every step (e.g. before the first termination): union of the
+        # names, NaN where a step's dict had no such key
+        names = sorted(set().union(*[set(d) for d in snaps["rc"]]))
+        out["snap_rc"] = np.stack([np.stack([d.get(k, np.full(N, np.nan, dtype=np.float32)) for k in names]) for d in snaps["rc"]])
+        out["snap_rc_names"] = json.dumps(names)
+    sparse_l1r = name in ("blind_wide", "base_wide", "blind_long")
+    if sparse_l1r:
+        idx, n_used = [], 0
+        for s_ in l1_reset:
+            idx.append(n_used if s_ is not None else -1)
+            n_used += s_ is not None
+        out["l1r_index"] = np.array(idx)
     fields = list(l1_main[0].keys())
     for f in fields:
         out[f"l1_{f}"] = np.stack([s[f] for s in l1_main])
-        out[f"l1r_{f}"] = np.stack([(s[f] if s is not None else np.zeros_like(l1_main[0][f])) for s in l1_reset])
+        if sparse_l1r:   # new scenarios: the reset-step state only for the steps that had one (l1r_index: step -> row, -1 = none)
+            used_rows = [s_[f] for s_ in l1_reset if s_ is not None]
+            out[f"l1r_{f}"] = np.stack(used_rows) if used_rows else np.zeros((0,) + l1_main[0][f].shape, dtype=np.float32)
+        else:
+            out[f"l1r_{f}"] = np.stack([(s[f] if s is not None else np.zeros_like(l1_main[0][f])) for s in l1_reset])
         out[f"l1reset0_{f}"] = reset0_l1[f]
     # a few dictionary components to pin obs_all rows that are not in obs_buf
     od = env.obs_dict
@@ -566,9 +691,18 @@ def main():
     sys.path.insert(0, REF)
     n = pin_quaternion_standins()
     print(f"reference utils/test_coordinate_transforms.py: all cases passed against stand-ins ({n} PASSED lines)")
-    for name, N, T, seed in (("blind_default", 8, 40, 11), ("blind_fast", 12, 60, 12),
-                             ("base_default", 6, 45, 13), ("base_position", 6, 20, 14)):
-        out = run_scenario(name, N, T, seed)
+    # round-1 scenarios (N = 6..12) + round-2 scenarios: two workgroups incl. a padded one (N = 70), explicit reset_idx
+    # events, per-step snapshots of every obs_dict key / reward component, and a default-length FSM run (stage 2, 3, success)
+    table = [("blind_default", 8, 40, 11, None, ()), ("blind_fast", 12, 60, 12, None, ()),
+             ("base_default", 6, 45, 13, None, ()), ("base_position", 6, 20, 14, None, ()),
+             ("blind_wide", 70, 26, 15, {9: [3, 17, 65, 69], 20: [0, 64]}, (2, 6, 8, 13, 17, 21, 25)),
+             ("base_wide", 70, 10, 16, {4: [1, 66]}, (0, 5, 9)),
+             ("blind_long", 6, 345, 17, None, (197, 198, 199, 226, 227, 228, 327, 328, 344))]
+    only = set(sys.argv[1:])
+    for name, N, T, seed, events, snap in table:
+        if only and name not in only:
+            continue
+        out = run_scenario(name, N, T, seed, events=events, snap_steps=snap)
         path = os.path.join(HERE, f"l2_{name}.npz")
         np.savez_compressed(path, **out)
         done = out["done"]

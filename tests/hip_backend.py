@@ -52,10 +52,8 @@ class HipBackend:
         self.core.run_stage(_abi.STAGE["POST"] + 100)
 
     def l2_step_no_reset(self):
-        if self._posted:
-            self.core.run_stage(_abi.STAGE["FINALIZE"])
         self.core.run_stage(_abi.STAGE["POST"])
-        self._posted = True
+        self.core.run_stage(_abi.STAGE["FINALIZE"])     # step statistics; opens the next staged control step
 
     def reset_flagged_no_physics(self):
         self.core.run_stage(_abi.STAGE["RESET"])        # flagged envs, no device-side gate, no physics

@@ -11,7 +11,7 @@ from dexrobot_isaac_amd.config import build_sim_config, default_cfg
 
 pytestmark = pytest.mark.gpu
 
-SCENARIOS = ["blind_default", "blind_fast", "base_default", "base_position"]
+from tests.l2_replay import ALL_SCENARIOS as SCENARIOS  # noqa: E402
 
 
 def _mk(task, n, **over):
@@ -35,6 +35,13 @@ def test_hip_l2_replays_reference_golden(golden_dir, name):
     hb = HipBackend(sc, model.to_struct())
     err = replay(hb, npz)     # obs within 2e-5 abs / 1e-5 rel, rewards 2e-6 rel, done exact
     assert err["obs"] < 2e-5 and err["active_prev_targets"] < 1e-6
+    # the replay also compared, ON THE HIP PATH: every final obs_dict component and reward component of the scenario, the
+    # per-step success / failure / timeout rates and consecutive successes, and in the round-2 scenarios (N = 70: two
+    # workgroups, one of them padded; default-length FSM) the explicit reset_idx(ids) events and per-step snapshots of every
+    # obs_dict key and every reward component
+    assert any(k.startswith("final:") for k in err) and any(k.startswith("final_rc:") for k in err) and "stats" in err
+    if name in ("blind_wide", "base_wide"):
+        assert any(k.startswith("ev:") for k in err) and any(k.startswith("snap:") for k in err) and any(k.startswith("snap_rc:") for k in err)
 
 
 def _random_state(rng, model, n, near_box=True):
@@ -630,3 +637,39 @@ def test_hip_error_is_a_small_multiple_of_fp32_roundoff():
     for f, r in report.items():
         assert r[1] <= c * r[0] + 1e-7, (f, r)
         assert r[3] <= c * r[2] + 1e-6, (f, r)
+
+
+@pytest.mark.parametrize("task", ["BlindGrasping", "BaseTask"])
+def test_fused_step_equals_staged_step_bitwise(task):
+    """dexsim_step (one fused launch: action block + 4 sub-steps + post block on 7 waves, then the gated twin) against the
+    three staged calls (k_actions, k_physics4 without the blocks, k_post on 8 waves + gated launch) from identical state,
+    over steps that include in-step resets: every output and the whole carried state must be BIT-identical -- the fused
+    production post block is thereby tied to the stand-alone stages that the golden replays exercise."""
+    import torch
+    from tests.hip_backend import HipBackend
+    n = 200                                                  # 4 workgroups, the last one padded
+    sc, model = _mk(task, n, **{"env.episodeLength": 7})
+    ms = model.to_struct()
+    a, b = HipBackend(sc, ms), HipBackend(sc, ms)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    fields = ("q", "qd", "targets", "obs_all", "rew_comp", "rew", "reset_flag", "episode_step", "active_prev_targets",
+              "prev_actions", "prev_dof_pos", "contact_duration_steps", "prev_contact_binary", "cforce", "cf5", "site_pose",
+              "reset_count", "term_timeout", "failure_reason", "prev_finger_dof_vel", "prev_hand_vel") + \
+             (("box_pos", "box_quat", "box_lin", "current_stage", "time_in_stage") if task == "BlindGrasping" else ())
+    resets = 0
+    for t in range(10):
+        act = 2 * torch.rand(n, 18, device="cuda:0", generator=g) - 1
+        a.core.step(act)
+        b.core.process_actions(act)
+        b.core.physics_step(False)
+        b.core.post_physics(False)
+        torch.cuda.synchronize()
+        assert torch.equal(a.core.obs_buf, b.core.obs_buf), t
+        assert torch.equal(a.core.rew_buf, b.core.rew_buf) and torch.equal(a.core.reset_buf, b.core.reset_buf)
+        assert torch.equal(a.core.dof_state, b.core.dof_state) and torch.equal(a.core.masks, b.core.masks)
+        assert torch.equal(a.core.stats[:18], b.core.stats[:18])
+        for f in fields:
+            assert np.array_equal(a.get(f), b.get(f)), (t, f)
+        resets += int(a.core.reset_buf.sum())
+    assert resets >= n                                       # time-outs at step 6: the reset path was part of the comparison

@@ -1,5 +1,6 @@
 """The CPU oracle's L2 restatement against golden vectors produced by the reference's own Python
 (tests/golden/generate_golden.py).  This is what PINS the oracle (prompt ③)."""
+import json
 import os
 
 import numpy as np
@@ -9,7 +10,7 @@ from dexrobot_isaac_amd.config import OBS_KEYS, REWARD_TERMS, build_sim_config, 
 from oracle.oracle import Oracle
 from tests.l2_replay import replay, scenario_config
 
-SCENARIOS = ["blind_default", "blind_fast", "base_default", "base_position"]
+from tests.l2_replay import ALL_SCENARIOS as SCENARIOS  # noqa: E402
 
 
 def _load(golden_dir, name):
@@ -23,27 +24,12 @@ def test_oracle_replays_reference_l2(golden_dir, name):
     o = Oracle(sc, model.to_struct())
     err = replay(o, npz)
     assert err["obs"] < 2e-5
-    # final obs_dict components that are not part of obs_buf
-    offs = obs_key_offsets()
-    oa = o.get("obs_all")
-    for key in ("hand_pose_arr_aligned", "fingertip_poses_hand", "fingerpad_poses_hand", "contact_forces",
-                "contact_force_magnitude", "all_finger_dof_vel", "all_finger_dof_target", "active_rule_targets",
-                "finger_to_object_distances", "finger_to_object_height_diff", "hand_to_object_distance",
-                "grasp_state", "grasp_duration", "thumb_contact", "other_fingers_contact"):
-        f = f"final_{key}"
-        if f in npz.files:
-            off, dim = offs[key]
-            np.testing.assert_allclose(oa[off:off + dim].T, npz[f], atol=2e-5, rtol=1e-5, err_msg=key)
-    # reward components of the last step
-    rc = o.get("rew_comp")
-    for i, term in enumerate(REWARD_TERMS):
-        f = f"final_rc_{term}"
-        if f in npz.files:
-            np.testing.assert_allclose(rc[i], npz[f], atol=1e-5, rtol=1e-5, err_msg=term)
-            np.testing.assert_allclose(rc[26 + i], npz[f"final_rc_{term}_weighted"], atol=2e-3, rtol=2e-6)
-    for j, nme in enumerate(("success", "failure_penalty", "timeout_penalty")):
-        np.testing.assert_allclose(rc[53 + j], npz[f"final_rc_termination_{nme}"], atol=0)
-        np.testing.assert_allclose(rc[56 + j], npz[f"final_rc_termination_{nme}_weighted"], atol=1e-4)
+    # (replay also checks, on this backend: the end-of-scenario snapshot of the obs_dict components outside obs_buf and of
+    # every reward component, the per-step success / failure / timeout rates and consecutive successes, and -- in the
+    # round-2 scenarios -- explicit reset_idx(ids) events and per-step snapshots of every obs_dict key / reward component)
+    assert any(k.startswith("final:") for k in err) and any(k.startswith("final_rc:") for k in err)
+    if name in ("blind_wide", "base_wide"):
+        assert any(k.startswith("ev:") for k in err) and any(k.startswith("snap:") for k in err)
 
 
 def test_scenarios_cover_the_branches(golden_dir):
@@ -58,3 +44,11 @@ def test_scenarios_cover_the_branches(golden_dir):
     assert (npz["stats"][:, 0] > 0).any() and (npz["stats"][:, 1] > 0).any()
     base = _load(golden_dir, "base_default")
     assert base["done"].sum() == 12          # timeouts at episodeLength - 1
+    # round 2: default-length FSM (stage 1 = 200 control steps) reaching stage 2, stage 3 and grasp_lift_success
+    lng = _load(golden_dir, "blind_long")
+    ts = lng["task_state"]
+    assert (ts[:, 0] == 2).sum() > 20 and (ts[:, 0] == 3).sum() > 50 and (lng["rew"] > 1500).any()
+    assert json.loads(str(lng["cfg_overrides"])) == {}
+    # ... and two workgroups incl. a padded one, with explicit reset_idx events
+    wide = _load(golden_dir, "blind_wide")
+    assert int(wide["N"]) == 70 and len(wide["ev_step"]) == 2 and wide["done"].sum() > 200
