@@ -432,10 +432,12 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
     q2mat(Rb, e->box_quat);
     hb[0] = hb[1] = hb[2] = (real)0.5 * cfg->box_size;
     real mu_bg = (real)0.5 * (e->box_mu + cfg->ground_friction);
+    /* at most 4 box/ground contacts (a cube touches a plane with at most 4 corners; more only when it is buried), in
+     * corner-index order */
     for (int i = 0; i < 8; i++) {
       real l[3] = {(i & 1) ? hb[0] : -hb[0], (i & 2) ? hb[1] : -hb[1], (i & 4) ? hb[2] : -hb[2]}, p[3];
       m3v(p, Rb, l); v3add(p, p, e->box_pos);
-      if (p[2] < co) push_contact(e, 2, -1, p, zup, p[2] - rest, mu_bg);
+      if (p[2] < co && e->ncontact < 4) push_contact(e, 2, -1, p, zup, p[2] - rest, mu_bg);
     }
   }
   real mu_hg = (real)0.5 * (m->hand_friction + cfg->ground_friction);
@@ -464,9 +466,11 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
           if (seg_box_dfdt(a, d, mdl, hb) > 0) hi = mdl; else lo = mdl;
         }
         real ts = (real)0.5 * (lo + hi);
-        real tc[3] = {0, 1, ts};
-        int ntc = (ts > (real)0.02 && ts < (real)0.98) ? 3 : 2;
-        for (int s = 0; s < ntc; s++) {
+        /* closest feature first (axis point nearest to the box, snapped to an end within 2 % of it), then the far end of
+         * the axis: at most 2 contacts per capsule/box pair (round 1 sampled both ends + the closest point) */
+        real tp = ts <= (real)0.02 ? (real)0 : (ts >= (real)0.98 ? (real)1 : ts);
+        real tc[2] = {tp, tp < (real)0.5 ? (real)1 : (real)0};
+        for (int s = 0; s < 2; s++) {
           real P[3] = {a[0] + tc[s] * d[0], a[1] + tc[s] * d[1], a[2] + tc[s] * d[2]}, nl[3], pl[3], gr;
           sphere_box(P, r, hb, nl, pl, &gr);
           if (gr < co) {

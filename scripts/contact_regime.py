@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("DEXSIM_LIB"):               # experiments: a variant build of the library
+    from dexrobot_isaac_amd import _lib
+    _lib.LIB_PATH = os.environ["DEXSIM_LIB"]
 from dexrobot_isaac_amd.config import build_sim_config, default_cfg  # noqa: E402
 from dexrobot_isaac_amd.core import DexSimCore  # noqa: E402
 

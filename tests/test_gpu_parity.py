@@ -579,7 +579,7 @@ def test_config5_dr_8192_with_reset_churn():
     np.testing.assert_allclose(hb.get("box_mu"), o.get("box_mu"), rtol=5e-7)
     np.testing.assert_allclose(hb.reset(), o.reset(), atol=2e-4)
     rng = np.random.default_rng(31)
-    k = rng.integers(170, 200, (1, n))                      # stage-1 clocks: every env fails the pre-grasp check within 30 steps
+    k = rng.integers(173, 200, (1, n))                      # stage-1 clocks: every env fails the pre-grasp check within 30 steps
     for b in (o, hb):
         b.set("episode_step", k)
         b.set("time_in_stage", k * float(sc.control_dt))
@@ -633,7 +633,7 @@ def test_hip_error_is_a_small_multiple_of_fp32_roundoff():
     print("\nfield: p99.9 |f32-f64|, p99.9 |HIP-f64|, max |f32-f64|, max |HIP-f64|")
     for f, r in report.items():
         print(f"  {f:8s} {r[0]:.3e} {r[1]:.3e} {r[2]:.3e} {r[3]:.3e}")
-    c = 8.0
+    c = 2.5     # measured round 2: 1.0-1.5 for every field (profiles/round2_*/README.md)
     for f, r in report.items():
         assert r[1] <= c * r[0] + 1e-7, (f, r)
         assert r[3] <= c * r[2] + 1e-6, (f, r)
