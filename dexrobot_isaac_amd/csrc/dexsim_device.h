@@ -20,7 +20,7 @@
   /* dynamics -> contact-solve interface (one sub-step) */                                                  \
   X(float, jframe, 156) X(float, ufree, 32) X(float, fac_sinv, 21) X(float, fac_finv, 50)                   \
   X(float, fac_g, 120) X(int, ncontact, 1) X(float, cgeom, DEXSIM_KMAX * 8) X(int, ccode, DEXSIM_KMAX)      \
-  X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28) X(float, cbias, DEXSIM_KMAX) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * 15 * 9)                                         \
+  X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28 + 4) X(float, cbias, DEXSIM_KMAX) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * 15 * 9)                                         \
   /* L2 state (ActionProcessor / ObservationEncoder / task / RewardCalculator / TerminationManager) */      \
   X(float, active_prev_targets, 18) X(float, active_rule_targets, 18) X(float, prev_actions, 18)            \
   X(float, actions, 18) X(float, prev_dof_pos, 26)                                                          \
@@ -44,6 +44,8 @@ struct Arena {
 };
 
 #define CROW_W 28 /* words per contact row: t6 jf4 St6 Fj4 d3 rxd3 Dinv pad */
+// crowq: the rows of streamed hand contacts in the quad layout of the LDS row store ([quad][env] of float4, 21 quads per
+// contact), followed by ONE always-zero quad row (index KMAX * 21) that lanes without the contact read instead
 
 // per-joint constants packed as one 128-byte record: a wave fetches everything it needs about joint j with two
 // s_load_dwordx16 instead of ~12 scattered scalar loads (the base-chain walk was scalar-load-latency bound)

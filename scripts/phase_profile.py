@@ -15,8 +15,9 @@ from dexrobot_isaac_amd.build import CSRC  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "libdexsim_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17", "-DDEXSIM_PROFILE_PHASES",
-                       "-o", out, os.path.join(CSRC, "dexsim.hip")], cwd=CSRC)
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17", "-DDEXSIM_PROFILE_PHASES"] +
+                      os.environ.get("DEXSIM_EXTRA_DEFS", "").split() + [
+                       "-o", out, os.path.join(CSRC, "dexsim.hip")], cwd=CSRC)   # DEXSIM_EXTRA_DEFS: experiment switches (-DEXP_...)
 _lib.LIB_PATH = out
 from dexrobot_isaac_amd.config import build_sim_config, default_cfg  # noqa: E402
 from dexrobot_isaac_amd.core import DexSimCore  # noqa: E402
@@ -28,13 +29,15 @@ sc, model = build_sim_config(cfg)
 core = DexSimCore(sc, model.to_struct(), "cuda:0")
 core.reset()
 a = 2 * torch.rand(n, 18, device="cuda:0") - 1
-for _ in range(10):
-    core.step(a)
-if len(sys.argv) > 2:   # contact-rich regime: python scripts/phase_profile.py 4096 -0.40  (hand base lowered onto the box)
+if len(sys.argv) <= 2:
+    for _ in range(10):
+        core.step(a)
+if len(sys.argv) > 2:   # contact-rich regime: python scripts/phase_profile.py 4096 -0.40  (scripts/contact_regime.py's state)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
     q = core.field("q")
     q.zero_()
     q[2] = float(sys.argv[2])
-    q[6:] = 0.3 * torch.rand(20, n, device="cuda:0")
+    q[6:] = 0.3 * torch.rand(20, n, device="cuda:0", generator=g)
     core.field("qd").zero_()
     core.field("targets").copy_(q)
     for _ in range(20):
@@ -43,11 +46,12 @@ if len(sys.argv) > 2:   # contact-rich regime: python scripts/phase_profile.py 4
 core.run_stage(_abi.STAGE["SUBSTEP"])
 torch.cuda.synchronize()
 crow = core.field("crow").view(torch.int32).cpu().numpy()      # stamps of lane 0 of every block: rows wv*8 + k
-names = ["base chain", "phase1 fingers|palm", "phase2 schur|narrow", "phase3 rows", "phase4 sweeps", "phase5 integrate", "publish"]
+names = ["base chain", "phase1 fingers|palm", "phase2 schur|narrow", "phase3 rows", "phase4 sweeps", "phase5 integrate", "publish",
+         "(general path) end of sweep 1 / wave 6: of its first box block"]
 lanes = np.arange(0, n, 64)
 print(f"N={n}: cycles since kernel start at each boundary, median over {len(lanes)} workgroups (s_memtime @100 MHz ticks x?)")
 for wv in range(7):
-    st = np.array([[crow[wv * 8 + k, e] for k in range(7)] for e in lanes])
+    st = np.array([[crow[wv * 8 + k, e] for k in range(8)] for e in lanes])
     med = np.median(st, axis=0)
     print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))
 
