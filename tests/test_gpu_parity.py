@@ -673,3 +673,52 @@ def test_fused_step_equals_staged_step_bitwise(task):
             assert np.array_equal(a.get(f), b.get(f)), (t, f)
         resets += int(a.core.reset_buf.sum())
     assert resets >= n                                       # time-outs at step 6: the reset path was part of the comparison
+
+
+def test_level2_gym_shim_matches_fused_step():
+    """INTEGRATION.md level 2 (tests/dexsim_gym_shim.py: the gymapi subset of the reference's step path over the C-ABI):
+    the reference-style sequence -- targets uploaded with set_dof_position_target_tensor, gym.simulate + fetch_results +
+    refreshes, then the post-physics stage -- must reproduce the fused single-launch step bit for bit; the indexed
+    setters must teleport exactly the listed envs."""
+    import torch
+    from tests.dexsim_gym_shim import DexSimGym
+    from tests.hip_backend import HipBackend
+    n = 130
+    sc, model = _mk("BlindGrasping", n, **{"env.episodeLength": 6})
+    ms = model.to_struct()
+    a, gym = HipBackend(sc, ms), DexSimGym(sc, ms)
+    b = gym.core
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    for t in range(8):
+        act = 2 * torch.rand(n, 18, device="cuda:0", generator=g) - 1
+        a.core.step(act)
+        # level 2: the action stage produces full_dof_targets (here the device stage; the reference's own Python would),
+        # the upload goes through the gym call, then simulate / fetch / refresh, then the post-physics stage
+        b.process_actions(act)
+        gym.set_dof_position_target_tensor(None, b.full_dof_targets.clone())
+        gym.simulate(None); gym.fetch_results(None, True)
+        gym.refresh_dof_state_tensor(None); gym.refresh_actor_root_state_tensor(None)
+        b.post_physics(False)
+        torch.cuda.synchronize()
+        assert torch.equal(a.core.obs_buf, b.obs_buf) and torch.equal(a.core.rew_buf, b.rew_buf), t
+        assert torch.equal(a.core.reset_buf, b.reset_buf) and torch.equal(a.core.dof_state, gym.dof_state)
+        assert torch.equal(a.core.root_state, gym.actor_root_state)
+    assert int(a.core.field("reset_count").sum()) > n            # time-outs: the reset path was part of it
+    gym.refresh_rigid_body_state_tensor(None)
+    a.core.refresh_body_states()
+    torch.cuda.synchronize()
+    assert torch.equal(gym.rigid_body_state, a.core.rigid_body_states) and torch.equal(gym.net_contact_force, a.core.contact_forces_all)
+    # indexed setters: global actor indices (2 actors per env: hand = 2 e, box = 2 e + 1)
+    q_before = b.field("q").clone()
+    gym.dof_state[:, :, 0] = 0.05
+    gym.set_dof_state_tensor_indexed(None, gym.dof_state, torch.tensor([2 * 3, 2 * 129], dtype=torch.int32, device="cuda:0"), 2)
+    torch.cuda.synchronize()
+    q_after = b.field("q")
+    assert torch.allclose(q_after[:, [3, 129]], torch.full((26, 2), 0.05, device="cuda:0"))
+    keep = [i for i in range(n) if i not in (3, 129)]
+    assert torch.equal(q_after[:, keep], q_before[:, keep])
+    gym.actor_root_state[:, 1, :3] = torch.tensor([0.01, 0.02, 0.3], device="cuda:0")
+    gym.set_actor_root_state_tensor_indexed(None, gym.actor_root_state, torch.tensor([2 * 7 + 1], dtype=torch.int32, device="cuda:0"), 1)
+    torch.cuda.synchronize()
+    assert torch.allclose(b.field("box_pos")[:, 7], torch.tensor([0.01, 0.02, 0.3], device="cuda:0"))
