@@ -6,7 +6,7 @@ a drifted mirror fails loudly instead of corrupting memory.
 import ctypes as C
 
 NJ, NBASE, NFINGER, NFJ, NACT = 26, 6, 5, 4, 18
-NSITE, NCAP, NFSLOT, KMAX = 11, 18, 17, 16
+NSITE, NCAP, NFSLOT, KMAX = 11, 18, 17, 24
 FSLOT_PALM, FSLOT_BOX = 15, 16
 NRESET_SAMPLES = 29
 MAX_OBS_SEG = 40

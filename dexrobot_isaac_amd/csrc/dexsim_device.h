@@ -20,7 +20,7 @@
   /* dynamics -> contact-solve interface (one sub-step) */                                                  \
   X(float, jframe, 156) X(float, ufree, 32) X(float, fac_sinv, 21) X(float, fac_finv, 50)                   \
   X(float, fac_g, 120) X(int, ncontact, 1) X(float, cgeom, DEXSIM_KMAX * 8) X(int, ccode, DEXSIM_KMAX)      \
-  X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28 + 4) X(float, cbias, DEXSIM_KMAX) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * 15 * 9)                                         \
+  X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28 + 4) X(float, cbias, DEXSIM_KMAX) X(float, clam, DEXSIM_KMAX * 3) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * 15 * 9)                                         \
   /* L2 state (ActionProcessor / ObservationEncoder / task / RewardCalculator / TerminationManager) */      \
   X(float, active_prev_targets, 18) X(float, active_rule_targets, 18) X(float, prev_actions, 18)            \
   X(float, actions, 18) X(float, prev_dof_pos, 26)                                                          \

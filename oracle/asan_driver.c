@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     for (int e = 0; e < n; e++) { q[2 * n + e] = -0.40; for (int j = 6; j < rows; j++) q[j * n + e] = 0.05 * ((j + e) % 6); }
     orc_set_field(h, "q", q); orc_set_field(h, "targets", q);
     for (int t = 0; t < 4; t++) orc_physics_step(h);
-    double c[16 * 10];
+    double c[DEXSIM_KMAX * 10];
     int k = orc_get_contacts(h, 0, c);
     csum += k;
     free(q);

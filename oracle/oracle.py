@@ -91,7 +91,7 @@ class Oracle:
         self.lib.orc_set_field(self.h, name.encode(), v.ctypes.data)
 
     def contacts(self, env):
-        out = np.zeros((16, 10), dtype=np.float64)
+        out = np.zeros((64, 10), dtype=np.float64)     # >= DEXSIM_KMAX rows
         k = self.lib.orc_get_contacts(self.h, env, out.ctypes.data)
         return out[:k]
 

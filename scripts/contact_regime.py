@@ -22,7 +22,10 @@ sc, model = build_sim_config(cfg)
 core = DexSimCore(sc, model.to_struct(), "cuda:0")
 core.reset()
 g = torch.Generator(device="cuda:0").manual_seed(3)
-for label, z in (("hand clear (z offset 0)", 0.0), ("hand low over the box (z offset -0.40)", -0.40), ("pressing (z offset -0.43)", -0.43)):
+regimes = (("hand clear (z offset 0)", 0.0), ("hand low over the box (z offset -0.40)", -0.40), ("pressing (z offset -0.43)", -0.43))
+if len(sys.argv) > 2 and sys.argv[2] == "contact-only":      # under rocprofv3: only the bench line's contact_rich state is traced
+    regimes = regimes[1:2]
+for label, z in regimes:
     q = core.field("q")
     q.zero_()
     q[2] = z

@@ -27,6 +27,11 @@ def short(name):
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+cstats = glob.glob(os.path.join(src, "contact", "**", "*kernel_stats.csv"), recursive=True)
+if cstats:                                # kernel trace of the contact-rich regime (scripts/contact_regime.py ... contact-only)
+    shutil.copy(cstats[0], os.path.join(dst, "contact_rich_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "contact.log")):
+    shutil.copy(os.path.join(src, "contact.log"), os.path.join(dst, "contact_regime.txt"))
 rows = {}
 for which in ("fetch", "write"):
     f = glob.glob(os.path.join(src, which, "**", "*counter_collection.csv"), recursive=True)
