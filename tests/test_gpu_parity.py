@@ -722,3 +722,47 @@ def test_level2_gym_shim_matches_fused_step():
     gym.set_actor_root_state_tensor_indexed(None, gym.actor_root_state, torch.tensor([2 * 7 + 1], dtype=torch.int32, device="cuda:0"), 1)
     torch.cuda.synchronize()
     assert torch.allclose(b.field("box_pos")[:, 7], torch.tensor([0.01, 0.02, 0.3], device="cuda:0"))
+
+
+def test_saturated_contact_list_matches_oracle():
+    """The whole contact list in use: hands lowered until fingers and palm lie on box and ground -- every env reaches
+    DEXSIM_KMAX = 24 contacts (4 box/ground + 20 hand contacts in priority order, the rest truncated), i.e. hand slots
+    beyond the LDS row slots (rows streamed from the arena) and list entries beyond the 16 LDS header / impulse slots
+    (kept in the sweeping wave's registers).  Contact lists must be identical, the state after a full physics step within
+    the teacher-forced tolerances."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    from dexrobot_isaac_amd import _abi
+    n = 192
+    sc, model = _mk("BlindGrasping", n)
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms), HipBackend(sc, ms)
+    rng = np.random.default_rng(2)
+    q = np.zeros((26, n))
+    q[2] = -0.42 + rng.uniform(-0.02, 0.02, n)
+    q[3:6] = rng.uniform(-0.15, 0.15, (3, n))
+    q[6:] = rng.uniform(0, 0.3, (20, n))
+    st = dict(q=q, qd=0 * q, targets=q, box_pos=np.array([[0.0], [0.0], [0.0255]]) + 0 * q[:3],
+              box_quat=np.array([[0.0], [0.0], [0.0], [1.0]]) + 0 * q[:4], box_lin=0 * q[:3], box_ang=0 * q[:3])
+    for k, v in st.items():
+        o.set(k, v)
+        hb.set(k, v)
+    o.substep(last=True)
+    hb.substep(last=True)
+    nc_o, nc_h = o.get("ncontact")[0], hb.get("ncontact")[0]
+    assert (nc_o == nc_h).all() and nc_o.max() == _abi.KMAX and (nc_o > 16).mean() > 0.9
+    for e in range(0, n, 7):
+        co, ch = o.contacts(e), hb.contacts(e)
+        assert co.shape == ch.shape and (co[:, 8] == ch[:, 8]).all()
+        hand = co[:, 8] != 2
+        assert (co[hand, 9] == ch[hand, 9]).all()
+        np.testing.assert_allclose(ch[:, :8], co[:, :8], atol=2e-6)
+    np.testing.assert_allclose(hb.get("q"), o.get("q"), atol=2e-4)
+    np.testing.assert_allclose(hb.get("qd"), o.get("qd"), atol=1e-2, rtol=5e-3)      # 24 coupled contacts: PGS amplifies roundoff
+    np.testing.assert_allclose(hb.get("box_pos"), o.get("box_pos"), atol=2e-4)
+    np.testing.assert_allclose(hb.get("cforce"), o.get("cforce"), atol=0.5, rtol=5e-2)
+    # ... and three more full physics steps stay finite and in agreement on the list sizes
+    for _ in range(3):
+        o.physics_step()
+        hb.physics_step()
+    assert np.isfinite(hb.get("q")).all() and np.abs(hb.get("q") - o.get("q")).max() < 5e-3
