@@ -19,7 +19,7 @@ class HipBackend:
     def set(self, name, value):
         f = self.core.field(name)
         v = np.broadcast_to(np.asarray(value, dtype=np.float64), tuple(f.shape))
-        f.copy_(torch.as_tensor(np.ascontiguousarray(v)).to(f.dtype))
+        f.copy_(torch.as_tensor(np.array(v, copy=True)).to(f.dtype))
 
     def get(self, name):
         return self.core.field(name).detach().cpu().numpy().astype(np.float64)
