@@ -104,6 +104,9 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DEXSIM_BENCH_LAUNCH_PROBE"):     # tests/test_bench_launch.py: the launch logic without a GPU
+        print(f"probe rank {rank} local_rank {local_rank} world {world} master {os.environ.get('MASTER_ADDR')}", flush=True)
+        sys.exit(0)
 
     import torch
     import torch.distributed as dist

@@ -34,14 +34,15 @@ if len(sys.argv) <= 2:
         core.step(a)
 if len(sys.argv) > 2:   # contact-rich regime: python scripts/phase_profile.py 4096 -0.40  (scripts/contact_regime.py's state)
     g = torch.Generator(device="cuda:0").manual_seed(3)
-    q = core.field("q")
-    q.zero_()
-    q[2] = float(sys.argv[2])
-    q[6:] = 0.3 * torch.rand(20, n, device="cuda:0", generator=g)
-    core.field("qd").zero_()
-    core.field("targets").copy_(q)
-    for _ in range(20):
-        core.physics_step(False)
+    for z, nsteps in ((0.0, 120), (float(sys.argv[2]), 20)):      # the same sequence of states as scripts/contact_regime.py
+        q = core.field("q")
+        q.zero_()
+        q[2] = z
+        q[6:] = 0.3 * torch.rand(20, n, device="cuda:0", generator=g)
+        core.field("qd").zero_()
+        core.field("targets").copy_(q)
+        for _ in range(nsteps):
+            core.physics_step(False)
     print("contact regime: contacts/env mean %.2f max %d" % (core.field("ncontact").float().mean().item(), int(core.field("ncontact").max().item())))
 core.run_stage(_abi.STAGE["SUBSTEP"])
 torch.cuda.synchronize()
