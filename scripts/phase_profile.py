@@ -34,7 +34,7 @@ if len(sys.argv) <= 2:
         core.step(a)
 if len(sys.argv) > 2:   # contact-rich regime: python scripts/phase_profile.py 4096 -0.40  (scripts/contact_regime.py's state)
     g = torch.Generator(device="cuda:0").manual_seed(3)
-    for z, nsteps in ((0.0, 120), (float(sys.argv[2]), 20)):      # the same sequence of states as scripts/contact_regime.py
+    for z, nsteps in ((0.0, 120), (float(sys.argv[2]), 120)):     # the same sequence of states as scripts/contact_regime.py
         q = core.field("q")
         q.zero_()
         q[2] = z
