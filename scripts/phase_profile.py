@@ -55,6 +55,10 @@ for wv in range(7):
     st = np.array([[crow[wv * 8 + k, e] for k in range(8)] for e in lanes])
     med = np.median(st, axis=0)
     print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))
+    if wv == 0:   # the launch ends with its slowest workgroup
+        slow = st[np.argmax(st[:, 6])]
+        print("wave 0, slowest workgroup: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, slow)))
+        print("wave 0, publish stamp over workgroups: min %d  median %d  p90 %d  max %d" % (st[:, 6].min(), np.median(st[:, 6]), np.percentile(st[:, 6], 90), st[:, 6].max()))
 
 # k_post: per-wave stamps after phase A (helper tasks / wave-0 loads), phase B (wave-0 logic), the row flush and the
 # obs_buf flush; then wave 0's logic split (relative to the start of phase B)
