@@ -766,3 +766,32 @@ def test_saturated_contact_list_matches_oracle():
         o.physics_step()
         hb.physics_step()
     assert np.isfinite(hb.get("q")).all() and np.abs(hb.get("q") - o.get("q")).max() < 5e-3
+
+
+@pytest.mark.parametrize("substeps,iters", [(2, 8), (8, 32)], ids=["physics=fast", "8 sub-steps / 32 iterations"])
+def test_other_substep_counts_use_the_staged_path(substeps, iters):
+    """cfg/physics/fast.yaml (substeps 2, 8 position iterations) and a heavier setting in the direction of
+    cfg/physics/accurate.yaml (the reference's 32 x 32, shortened here): sub-step counts other than 4 run dexsim_step as
+    the staged launches (k_actions, `substeps` x k_substep, k_post, k_reset, gated physics, k_reset).  Whole control steps
+    with in-step resets against the oracle; the integer bookkeeping must agree exactly."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 130
+    sc, model = _mk("BlindGrasping", n, **{"sim.substeps": substeps, "sim.physx.num_position_iterations": iters, "env.episodeLength": 8})
+    assert int(sc.substeps) == substeps and int(sc.num_position_iterations) == iters
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms), HipBackend(sc, ms)
+    np.testing.assert_allclose(hb.reset(), o.reset(), atol=2e-4)
+    rng = np.random.default_rng(13)
+    worst = 0.0
+    for t in range(12):
+        a = (2 * rng.random((n, 18)) - 1).astype(np.float32)
+        oo, ro, do = o.step(a)
+        oh, rh, dh = hb.step(a)
+        assert (do == dh.astype(bool)).all(), t
+        assert hb.stats()[16] == o.stats()[16] and hb.stats()[17] == (2 if do.any() else 1)
+        worst = max(worst, float(np.abs(oh - oo).max()))
+        np.testing.assert_allclose(rh, ro, atol=2e-2, rtol=1e-4)
+    assert worst < 5e-3, worst
+    assert o.get("reset_count").sum() > n
+    np.testing.assert_allclose(hb.get("q"), o.get("q"), atol=5e-4)
