@@ -146,3 +146,57 @@ def test_philox_reset_stream_is_reproducible_and_uniform():
     assert np.array_equal(o2.get("initial_box_pos"), box)                        # same (seed, env, reset_count) key
     o2.reset()
     assert not np.array_equal(o2.get("initial_box_pos"), box)                    # next reset_count -> new draw
+
+
+def test_narrowphase_properties_of_the_round2_manifold():
+    """The contact manifold's specification (closest feature, <= 2 per capsule / box pair, <= 4 box / ground corners,
+    DEXSIM_KMAX entries) as properties of the lists the oracle produces, over a spread of hand poses on and around the box:
+    every contact point lies on the surface it claims, normals are unit and point from the box / the ground into the hand
+    body, gaps are consistent with the geometry, the list order is box/ground first, and no capsule has more than two box
+    contacts and two ground contacts."""
+    from dexrobot_isaac_amd import _abi
+    n = 64
+    o, model, sc = _mk(n=n, f64=True)
+    rng = np.random.default_rng(4)
+    q = np.zeros((26, n))
+    q[2] = rng.uniform(-0.46, -0.30, n)
+    q[:2] = rng.uniform(-0.03, 0.03, (2, n))
+    q[3:6] = rng.uniform(-0.2, 0.2, (3, n))
+    q[6:] = rng.uniform(0.0, 0.6, (20, n))
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    o.set("q", q); o.set("qd", 0 * q); o.set("targets", q)
+    o.set("box_pos", np.stack([0 * yaw, 0 * yaw, 0.025 + 0 * yaw]))
+    o.set("box_quat", np.stack([0 * yaw, 0 * yaw, np.sin(yaw / 2), np.cos(yaw / 2)]))
+    o.set("box_lin", np.zeros((3, n))); o.set("box_ang", np.zeros((3, n)))
+    bq, bp = o.get("box_quat").copy(), o.get("box_pos").copy()          # the pose the narrowphase sees (start of the sub-step)
+    o.substep(last=True)
+    hb = 0.5 * float(sc.box_size)
+    co, rest = float(sc.contact_offset), float(sc.rest_offset)
+    seen_two, total = 0, 0
+    for e in range(n):
+        c = o.contacts(e)
+        total += len(c)
+        assert len(c) <= _abi.KMAX
+        types = c[:, 8].astype(int)
+        nbg = int((types == 2).sum())
+        assert nbg <= 4 and (types[:nbg] == 2).all() and (types[nbg:] != 2).all()      # box/ground first, at most 4
+        np.testing.assert_allclose(np.linalg.norm(c[:, 3:6], axis=1), 1.0, atol=1e-9)
+        s, cq = bq[2, e], bq[3, e]                                       # yaw-only box orientation
+        R = np.array([[cq * cq - s * s, -2 * s * cq, 0], [2 * s * cq, cq * cq - s * s, 0], [0, 0, 1.0]])
+        for row in c:
+            p, nrm, gap, typ = row[0:3], row[3:6], row[6], int(row[8])
+            assert gap < co - rest + 1e-12                               # only contacts inside the contact offset are listed
+            if typ in (0, 2):                                            # on the ground plane, normal +z
+                np.testing.assert_allclose(nrm, [0, 0, 1], atol=1e-12)
+                if typ == 0:
+                    assert abs(p[2] - (gap + rest)) < 1e-9               # the point is the capsule's lowest point: z = gap + rest
+            else:                                                        # on the box surface
+                pl = R.T @ (p - bp[:, e])
+                assert np.max(np.abs(pl)) <= hb + 1e-9 and (np.abs(np.abs(pl) - hb) < 1e-9).any()
+                nl = R.T @ nrm
+                assert np.dot(nl, pl) > 0                                # outward
+        for cap in range(_abi.NCAP):
+            mine = c[(types != 2) & (c[:, 9] == cap)]
+            assert (mine[:, 8] == 1).sum() <= 2 and (mine[:, 8] == 0).sum() <= 2
+            seen_two += int((mine[:, 8] == 1).sum() == 2)
+    assert total > 6 * n and seen_two > 0                                # the sample has line contacts (two points on one capsule)
