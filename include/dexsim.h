@@ -37,6 +37,7 @@ extern "C" {
 #define DEXSIM_FSLOT_PALM 15
 #define DEXSIM_FSLOT_BOX  16
 #define DEXSIM_KMAX      24   /* max active contacts per env per sub-step (<= 4 box/ground + hand contacts in priority order) */
+#define DEXSIM_NWKEY 88      /* warm-start cache keys: (capsule * 2 + type) * 2 + sample for hand contacts (< 72), 80 + corner for box/ground */
 #define DEXSIM_NRESET_SAMPLES 29 /* rand draws of one reset (blind_grasping_task.py:449-547)            */
 #define DEXSIM_MAX_OBS_SEG 40
 

@@ -139,6 +139,7 @@ typedef struct OrcContact {
   real p[3], n[3], gap, mu;
   int type; /* 0 hand-ground, 1 hand-box, 2 box-ground */
   int cap;  /* capsule index for hand contacts */
+  int key;  /* warm-start key: hand contacts (cap * 2 + type) * 2 + sample, box/ground 80 + corner (< DEXSIM_NWKEY) */
 } OrcContact;
 
 typedef struct OrcEnv {
@@ -155,6 +156,10 @@ typedef struct OrcEnv {
   real cf5[5][3];
   int ncontact;
   OrcContact contact[KMAX];
+  /* warm-start cache: the impulses a contact key ended the previous sub-step with; an entry is valid while its tag equals
+   * the env's sub-step generation wgen (advanced by every sub-step and by a reset) */
+  real wlam[DEXSIM_NWKEY][3];
+  int wtag[DEXSIM_NWKEY], wgen;
   /* L2 state */
   real active_prev_targets[18], active_rule_targets[18], prev_actions[18], actions[18], prev_dof_pos[NJ];
   real contact_duration_steps[5], prev_contact_binary[5];
@@ -388,10 +393,11 @@ static inline void tangent_basis(const real* n, real* t1, real* t2) {
   v3cross(t2, n, t1);
 }
 
-static inline void push_contact(OrcEnv* e, int type, int cap, const real* p, const real* n, real gap, real mu) {
+static inline void push_contact(OrcEnv* e, int type, int cap, int sample, const real* p, const real* n, real gap, real mu) {
   if (e->ncontact >= KMAX) return;
   OrcContact* c = &e->contact[e->ncontact++];
   v3cpy(c->p, p); v3cpy(c->n, n); c->gap = gap; c->mu = mu; c->type = type; c->cap = cap;
+  c->key = type == 2 ? 80 + sample : (cap * 2 + type) * 2 + sample;
 }
 
 /* sphere (centre P in box frame, radius r) against the solid box of half extents h */
@@ -437,7 +443,7 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
     for (int i = 0; i < 8; i++) {
       real l[3] = {(i & 1) ? hb[0] : -hb[0], (i & 2) ? hb[1] : -hb[1], (i & 4) ? hb[2] : -hb[2]}, p[3];
       m3v(p, Rb, l); v3add(p, p, e->box_pos);
-      if (p[2] < co && e->ncontact < 4) push_contact(e, 2, -1, p, zup, p[2] - rest, mu_bg);
+      if (p[2] < co && e->ncontact < 4) push_contact(e, 2, -1, i, p, zup, p[2] - rest, mu_bg);
     }
   }
   real mu_hg = (real)0.5 * (m->hand_friction + cfg->ground_friction);
@@ -477,7 +483,7 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
             real pw[3], nw[3];
             m3v(pw, Rb, pl); v3add(pw, pw, e->box_pos);
             m3v(nw, Rb, nl);
-            push_contact(e, 1, c, pw, nw, gr - rest, mu_hb);
+            push_contact(e, 1, c, s, pw, nw, gr - rest, mu_hb);
           }
         }
       }
@@ -485,7 +491,7 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
     const real* ends[2] = {e0, e1};
     for (int s = 0; s < 2; s++) {
       real zl = ends[s][2] - r;
-      if (zl < co) { real p[3] = {ends[s][0], ends[s][1], zl}; push_contact(e, 0, c, p, zup, zl - rest, mu_hg); }
+      if (zl < co) { real p[3] = {ends[s][0], ends[s][1], zl}; push_contact(e, 0, c, s, p, zup, zl - rest, mu_hg); }
     }
   }
 }
@@ -558,6 +564,9 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     }
     cbias[k] = c->gap > 0 ? c->gap / h : -minr(-c->gap * cfg->erp / h, cfg->max_depenetration_velocity);
   }
+  static int legacy = -1;   /* development switch, removed once the kernels follow the round-2 solver */
+  if (legacy < 0) { const char* sv = getenv("ORC_LEGACY_SOLVER"); legacy = sv ? atoi(sv) : 1; }
+  if (legacy) {
   for (int it = 0; it < cfg->num_position_iterations; it++) {
     for (int k = 0; k < K; k++) {
       real mu = e->contact[k].mu;
@@ -572,6 +581,110 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
         lam[row] = nl;
         for (int i = 0; i < NV; i++) v[i] += Y[row][i] * dl;
       }
+    }
+  }
+  } else if (K > 0) {
+    /* ---- warm start: a contact that existed in the previous sub-step (same key) starts from the impulses it ended with;
+     * the free velocity receives their effect */
+    for (int k = 0; k < K; k++) {
+      int key = e->contact[k].key;
+      if (e->wtag[key] != e->wgen) continue;
+      for (int r = 0; r < 3; r++) {
+        real l0 = e->wlam[key][r];
+        lam[3 * k + r] = l0;
+        for (int i = 0; i < NV; i++) v[i] += Y[3 * k + r][i] * l0;
+      }
+    }
+    /* ---- block-parallel projected Gauss-Seidel with mass splitting (Tonge et al. 2012; PhysX's GPU solver is of this
+     * family).  Blocks: the box/ground contacts (block 6) and the hand contacts in list order, two by two, dealt round-robin
+     * to blocks 0-5 (hand contact j -> block (j / 2) % 6).  Within a sweep every block runs sequential projected Gauss-Seidel
+     * over its own contacts, starting from the common velocities; a body that several blocks touch -- the hand base
+     * (the 6 base DOFs at zero generalized finger momentum: T = [I; -G]), a finger's own DOFs, the box -- is shared out
+     * equally: a block sees 1/n of its mass, n = the number of blocks touching it; after the sweep the velocity changes of
+     * all blocks are added up.  Fixed point = the solution of the same LCP as plain Gauss-Seidel. */
+    int blk[KMAX], fng[KMAX], cntb[7] = {0, 0, 0, 0, 0, 0, 0}, boxb[7] = {0, 0, 0, 0, 0, 0, 0}, fb[5][7];
+    memset(fb, 0, sizeof fb);
+    int jh = 0;
+    for (int k = 0; k < K; k++) {
+      OrcContact* c = &e->contact[k];
+      fng[k] = c->type == 2 ? -1 : (m->cap_parent[c->cap] >= 6 ? (m->cap_parent[c->cap] - 6) / 4 : -1);
+      blk[k] = c->type == 2 ? 6 : (jh++ / 2) % 6;
+      cntb[blk[k]]++;
+      if (c->type != 0) boxb[blk[k]] = 1;
+      if (fng[k] >= 0) fb[fng[k]][blk[k]] = 1;
+    }
+    int nB = 0, nX = 0, nF[5];
+    for (int b = 0; b < 6; b++) nB += cntb[b] > 0;
+    for (int b = 0; b < 7; b++) nX += boxb[b];
+    for (int f = 0; f < 5; f++) { nF[f] = 0; for (int b = 0; b < 7; b++) nF[f] += fb[f][b]; if (nF[f] < 1) nF[f] = 1; }
+    if (nB < 1) nB = 1;
+    if (nX < 1) nX = 1;
+    /* T = [I; -G], G_f = Fhat_f^-1 C_f (Mh holds the Cholesky factor by now: take the blocks from M + the diagonal terms) */
+    real Tm[NJ][6];
+    memset(Tm, 0, sizeof Tm);
+    for (int i = 0; i < 6; i++) Tm[i][i] = 1;
+    for (int f = 0; f < 5; f++) {
+      real F[16], Cc[4][6];
+      for (int i = 0; i < 4; i++) {
+        int gi = 6 + 4 * f + i;
+        for (int j = 0; j < 4; j++) F[i * 4 + j] = M[gi][6 + 4 * f + j];
+        F[i * 4 + i] += m->armature[gi] + h * (m->kd[gi] + h * m->kp[gi]);
+        for (int j = 0; j < 6; j++) Cc[i][j] = M[gi][j];
+      }
+      cholesky(F, 4);
+      for (int j = 0; j < 6; j++) {
+        real col[4] = {Cc[0][j], Cc[1][j], Cc[2][j], Cc[3][j]};
+        chol_solve(F, 4, col);
+        for (int i = 0; i < 4; i++) Tm[6 + 4 * f + i][j] = -col[i];
+      }
+    }
+    /* response of a row inside its block: Y = T Y_B + P (P: the finger's own part) -> Ys = nB T Y_B + nF P, box part x nX */
+    static __thread real Ys[KMAX * 3][NV];
+    for (int row = 0; row < 3 * K; row++) {
+      for (int i = 0; i < NJ; i++) {
+        real t = 0;
+        for (int j = 0; j < 6; j++) t += Tm[i][j] * Y[row][j];
+        Ys[row][i] = i < 6 ? (real)nB * Y[row][i] : (real)nB * t + (real)nF[(i - 6) / 4] * (Y[row][i] - t);
+      }
+      for (int i = NJ; i < NV; i++) Ys[row][i] = (real)nX * Y[row][i];
+      real D = 0;
+      for (int i = 0; i < NV; i++) D += J[row][i] * Ys[row][i];
+      Dinv[row] = 1 / (D + (real)1e-9);
+    }
+    for (int it = 0; it < cfg->num_position_iterations; it++) {
+      real dsum[NV];
+      memset(dsum, 0, sizeof dsum);
+      for (int b = 0; b < 7; b++) {
+        if (!cntb[b]) continue;
+        real vb[NV], db[NV];
+        memcpy(vb, v, sizeof vb);
+        memset(db, 0, sizeof db);
+        for (int k = 0; k < K; k++) {
+          if (blk[k] != b) continue;
+          real mu = e->contact[k].mu;
+          for (int r = 0; r < 3; r++) {
+            int row = 3 * k + r;
+            real vr = 0;
+            for (int i = 0; i < NV; i++) vr += J[row][i] * vb[i];
+            real nl;
+            if (r == 0) nl = maxr(0, lam[row] - (vr + cbias[k]) * Dinv[row]);
+            else { real lim = mu * lam[3 * k]; nl = clampr(lam[row] - vr * Dinv[row], -lim, lim); }
+            real dl = nl - lam[row];
+            lam[row] = nl;
+            for (int i = 0; i < NV; i++) { vb[i] += Ys[row][i] * dl; db[i] += Y[row][i] * dl; }
+          }
+        }
+        for (int i = 0; i < NV; i++) dsum[i] += db[i];
+      }
+      for (int i = 0; i < NV; i++) v[i] += dsum[i];
+    }
+  }
+  if (!legacy) {
+    e->wgen++;
+    for (int k = 0; k < K; k++) {
+      int key = e->contact[k].key;
+      e->wtag[key] = e->wgen;
+      for (int r = 0; r < 3; r++) e->wlam[key][r] = lam[3 * k + r];
     }
   }
   /* net contact force per body, last sub-step only (contact_collection: 1 = CC_LAST_SUBSTEP) */
@@ -1006,6 +1119,7 @@ static void reset_env(const Oracle* o, OrcEnv* e, int idx) {
     for (int i = 0; i < 20; i++) e->q[6 + i] = u[9 + i] * (i == 0 ? c->thumb_rotation_range : c->other_finger_range);
   }
   e->reset_count++;
+  e->wgen++;   /* the warm-start cache does not survive a teleport */
   /* ActionProcessor.reset_targets (action_processor.py:524-568) */
   for (int i = 0; i < NJ; i++) e->targets[i] = e->q[i];
   extract_active_targets(e->q, e->active_prev_targets);
@@ -1192,6 +1306,7 @@ static const FieldDesc FIELDS[] = {
   {"site_pose", 77, 0, OFF(site_pose)}, {"hand_vel", 6, 0, OFF(hand_vel)}, {"cforce", 51, 0, OFF(cforce)},
   {"cf5", 15, 0, OFF(cf5)},
   {"ncontact", 1, 1, OFF(ncontact)},
+  {"wlam", DEXSIM_NWKEY * 3, 0, OFF(wlam)}, {"wtag", DEXSIM_NWKEY, 1, OFF(wtag)}, {"wgen", 1, 1, OFF(wgen)},
   {"active_prev_targets", 18, 0, OFF(active_prev_targets)}, {"active_rule_targets", 18, 0, OFF(active_rule_targets)},
   {"prev_actions", 18, 0, OFF(prev_actions)}, {"actions", 18, 0, OFF(actions)}, {"prev_dof_pos", NJ, 0, OFF(prev_dof_pos)},
   {"contact_duration_steps", 5, 0, OFF(contact_duration_steps)}, {"prev_contact_binary", 5, 0, OFF(prev_contact_binary)},
