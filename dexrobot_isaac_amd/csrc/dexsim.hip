@@ -329,7 +329,7 @@ static int launch_publish(dexsim_t h, int gate, int full, void* stream) {
 
 // LDS budget of the contact-solve kernel: stage the rows of as many contacts as fit next to u_f and the impulses.
 // At <= 1 wavefront per CU (num_envs <= 64 * #CUs) the whole 160 KiB is this wave's to use.
-static int solve_kstage(const DexSim* h) { return h->NS <= 64 * 256 ? 5 : 2; }   // 5: (20 + 7 KMAX + 5 x 84) words x 256 B = 152 KiB
+static int solve_kstage(const DexSim* h) { return h->NS <= 64 * 256 ? 4 : 2; }   // 4: (60 + 7 KMAX + 4 x 84) words x 256 B = 141 KiB
 static size_t solve_lds_bytes(int kstage) { return (size_t)SOLVE_LDS_WORDS(kstage) * 64 * sizeof(float); }
 
 static int launch_solve(dexsim_t h, int gate, int last, void* stream) {

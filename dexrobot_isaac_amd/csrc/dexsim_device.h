@@ -21,6 +21,8 @@
   X(float, jframe, 156) X(float, ufree, 32) X(float, fac_sinv, 21) X(float, fac_finv, 50)                   \
   X(float, fac_g, 120) X(int, ncontact, 1) X(float, cgeom, DEXSIM_KMAX * 8) X(int, ccode, DEXSIM_KMAX)      \
   X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28 + 4) X(float, cbias, DEXSIM_KMAX) X(float, clam, DEXSIM_KMAX * 3) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * 15 * 9)                                         \
+  /* warm-start cache: per contact key one float4 (impulses of the previous sub-step, tag), [key][env][4]; wgen = the env's sub-step generation */ \
+  X(float, wlam, DEXSIM_NWKEY * 4) X(int, wgen, 1) X(int, csplit, 1)                                         \
   /* L2 state (ActionProcessor / ObservationEncoder / task / RewardCalculator / TerminationManager) */      \
   X(float, active_prev_targets, 18) X(float, active_rule_targets, 18) X(float, prev_actions, 18)            \
   X(float, actions, 18) X(float, prev_dof_pos, 26)                                                          \
@@ -97,6 +99,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));   // maps onto the gfx950 
 typedef float f4 __attribute__((ext_vector_type(4)));   // 16-byte global accesses
 // 16-byte store to global memory (address-space 1: no FLAT instruction even when the pointer came from memory)
 __device__ __forceinline__ void st4_global(float* p, f4 v) { *(__attribute__((address_space(1))) f4*)p = v; }
+__device__ __forceinline__ void st4_global(float* p, float a, float b, float c, float d) { f4 v; v.x = a; v.y = b; v.z = c; v.w = d; st4_global(p, v); }
 
 struct V3 { float x, y, z; };
 struct Q4 { float x, y, z, w; };

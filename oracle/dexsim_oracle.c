@@ -139,7 +139,7 @@ typedef struct OrcContact {
   real p[3], n[3], gap, mu;
   int type; /* 0 hand-ground, 1 hand-box, 2 box-ground */
   int cap;  /* capsule index for hand contacts */
-  int key;  /* warm-start key: hand contacts (cap * 2 + type) * 2 + sample, box/ground 80 + corner (< DEXSIM_NWKEY) */
+  int key;  /* warm-start cache: hand contacts slot (cap * 2 + type) * 2 + sample; box/ground: the corner index (slot 80 + list index) */
 } OrcContact;
 
 typedef struct OrcEnv {
@@ -156,8 +156,9 @@ typedef struct OrcEnv {
   real cf5[5][3];
   int ncontact;
   OrcContact contact[KMAX];
-  /* warm-start cache: the impulses a contact key ended the previous sub-step with; an entry is valid while its tag equals
-   * the env's sub-step generation wgen (advanced by every sub-step and by a reset) */
+  /* warm-start cache: the impulses a contact ended the previous sub-step with.  Hand contacts: slot = (capsule, type, sample),
+   * valid while tag == 8 * wgen; box/ground contacts: slot 80 + list index k (k < 4), valid while tag == 8 * wgen + corner.
+   * wgen = the env's sub-step generation (advanced by every sub-step and by a reset) */
   real wlam[DEXSIM_NWKEY][3];
   int wtag[DEXSIM_NWKEY], wgen;
   /* L2 state */
@@ -397,7 +398,7 @@ static inline void push_contact(OrcEnv* e, int type, int cap, int sample, const 
   if (e->ncontact >= KMAX) return;
   OrcContact* c = &e->contact[e->ncontact++];
   v3cpy(c->p, p); v3cpy(c->n, n); c->gap = gap; c->mu = mu; c->type = type; c->cap = cap;
-  c->key = type == 2 ? 80 + sample : (cap * 2 + type) * 2 + sample;
+  c->key = type == 2 ? sample : (cap * 2 + type) * 2 + sample;
 }
 
 /* sphere (centre P in box frame, radius r) against the solid box of half extents h */
@@ -564,31 +565,13 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     }
     cbias[k] = c->gap > 0 ? c->gap / h : -minr(-c->gap * cfg->erp / h, cfg->max_depenetration_velocity);
   }
-  static int legacy = -1;   /* development switch, removed once the kernels follow the round-2 solver */
-  if (legacy < 0) { const char* sv = getenv("ORC_LEGACY_SOLVER"); legacy = sv ? atoi(sv) : 1; }
-  if (legacy) {
-  for (int it = 0; it < cfg->num_position_iterations; it++) {
-    for (int k = 0; k < K; k++) {
-      real mu = e->contact[k].mu;
-      for (int r = 0; r < 3; r++) {
-        int row = 3 * k + r;
-        real vr = 0;
-        for (int i = 0; i < NV; i++) vr += J[row][i] * v[i];
-        real nl;
-        if (r == 0) nl = maxr(0, lam[row] - (vr + cbias[k]) * Dinv[row]);
-        else { real lim = mu * lam[3 * k]; nl = clampr(lam[row] - vr * Dinv[row], -lim, lim); }
-        real dl = nl - lam[row];
-        lam[row] = nl;
-        for (int i = 0; i < NV; i++) v[i] += Y[row][i] * dl;
-      }
-    }
-  }
-  } else if (K > 0) {
+  if (K > 0) {
     /* ---- warm start: a contact that existed in the previous sub-step (same key) starts from the impulses it ended with;
      * the free velocity receives their effect */
     for (int k = 0; k < K; k++) {
-      int key = e->contact[k].key;
-      if (e->wtag[key] != e->wgen) continue;
+      const OrcContact* c = &e->contact[k];
+      int key = c->type == 2 ? 80 + k : c->key;
+      if (e->wtag[key] != 8 * e->wgen + (c->type == 2 ? c->key : 0)) continue;
       for (int r = 0; r < 3; r++) {
         real l0 = e->wlam[key][r];
         lam[3 * k + r] = l0;
@@ -596,19 +579,21 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
       }
     }
     /* ---- block-parallel projected Gauss-Seidel with mass splitting (Tonge et al. 2012; PhysX's GPU solver is of this
-     * family).  Blocks: the box/ground contacts (block 6) and the hand contacts in list order, two by two, dealt round-robin
-     * to blocks 0-5 (hand contact j -> block (j / 2) % 6).  Within a sweep every block runs sequential projected Gauss-Seidel
+     * family).  Blocks: the box/ground contacts (block 6) and the hand contacts in list order, in runs of two
+     * (of four when there are more than 12 of them): hand contact j -> block j / run, blocks 0-5.  Within a sweep every block runs sequential projected Gauss-Seidel
      * over its own contacts, starting from the common velocities; a body that several blocks touch -- the hand base
      * (the 6 base DOFs at zero generalized finger momentum: T = [I; -G]), a finger's own DOFs, the box -- is shared out
      * equally: a block sees 1/n of its mass, n = the number of blocks touching it; after the sweep the velocity changes of
      * all blocks are added up.  Fixed point = the solution of the same LCP as plain Gauss-Seidel. */
     int blk[KMAX], fng[KMAX], cntb[7] = {0, 0, 0, 0, 0, 0, 0}, boxb[7] = {0, 0, 0, 0, 0, 0, 0}, fb[5][7];
     memset(fb, 0, sizeof fb);
-    int jh = 0;
+    int jh = 0, nhand = 0;
+    for (int k = 0; k < K; k++) nhand += e->contact[k].type != 2;
+    const int run = nhand > 12 ? 4 : 2;   /* hand contacts per block: consecutive list entries stay together */
     for (int k = 0; k < K; k++) {
       OrcContact* c = &e->contact[k];
       fng[k] = c->type == 2 ? -1 : (m->cap_parent[c->cap] >= 6 ? (m->cap_parent[c->cap] - 6) / 4 : -1);
-      blk[k] = c->type == 2 ? 6 : (jh++ / 2) % 6;
+      blk[k] = c->type == 2 ? 6 : jh++ / run;
       cntb[blk[k]]++;
       if (c->type != 0) boxb[blk[k]] = 1;
       if (fng[k] >= 0) fb[fng[k]][blk[k]] = 1;
@@ -679,11 +664,12 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
       for (int i = 0; i < NV; i++) v[i] += dsum[i];
     }
   }
-  if (!legacy) {
+  {
     e->wgen++;
     for (int k = 0; k < K; k++) {
-      int key = e->contact[k].key;
-      e->wtag[key] = e->wgen;
+      const OrcContact* c = &e->contact[k];
+      int key = c->type == 2 ? 80 + k : c->key;
+      e->wtag[key] = 8 * e->wgen + (c->type == 2 ? c->key : 0);
       for (int r = 0; r < 3; r++) e->wlam[key][r] = lam[3 * k + r];
     }
   }

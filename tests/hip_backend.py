@@ -40,7 +40,7 @@ class HipBackend:
         out = np.zeros((k, 10))
         out[:, :8] = g
         out[:, 8] = code & 3
-        out[:, 9] = code >> 2
+        out[:, 9] = (code >> 2) & 31
         return out
 
     # -- pipeline stages
