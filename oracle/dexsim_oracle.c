@@ -579,29 +579,30 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
       }
     }
     /* ---- block-parallel projected Gauss-Seidel with mass splitting (Tonge et al. 2012; PhysX's GPU solver is of this
-     * family).  Blocks: the box/ground contacts (block 6) and the hand contacts in list order, in runs of two
-     * (of four when there are more than 12 of them): hand contact j -> block j / run, blocks 0-5.  Within a sweep every block runs sequential projected Gauss-Seidel
+     * family).  Blocks: the box/ground contacts together (block 12) and every hand contact on its own (hand contact j -> block
+     * j; with more than 12 hand contacts: pairs of consecutive list entries, j -> block j / 2; blocks 0-11).  Within a sweep every block runs sequential projected Gauss-Seidel
      * over its own contacts, starting from the common velocities; a body that several blocks touch -- the hand base
      * (the 6 base DOFs at zero generalized finger momentum: T = [I; -G]), a finger's own DOFs, the box -- is shared out
      * equally: a block sees 1/n of its mass, n = the number of blocks touching it; after the sweep the velocity changes of
      * all blocks are added up.  Fixed point = the solution of the same LCP as plain Gauss-Seidel. */
-    int blk[KMAX], fng[KMAX], cntb[7] = {0, 0, 0, 0, 0, 0, 0}, boxb[7] = {0, 0, 0, 0, 0, 0, 0}, fb[5][7];
+    int blk[KMAX], fng[KMAX], cntb[13] = {0}, boxb[13] = {0}, fb[5][13];
     memset(fb, 0, sizeof fb);
     int jh = 0, nhand = 0;
     for (int k = 0; k < K; k++) nhand += e->contact[k].type != 2;
-    const int run = nhand > 12 ? 4 : 2;   /* hand contacts per block: consecutive list entries stay together */
+    const int run = nhand > 12 ? 2 : 1;   /* hand contacts per block: every contact its own block; pairs of consecutive list
+                                            * entries when there are more than 12 (at most 12 hand blocks) */
     for (int k = 0; k < K; k++) {
       OrcContact* c = &e->contact[k];
       fng[k] = c->type == 2 ? -1 : (m->cap_parent[c->cap] >= 6 ? (m->cap_parent[c->cap] - 6) / 4 : -1);
-      blk[k] = c->type == 2 ? 6 : jh++ / run;
+      blk[k] = c->type == 2 ? 12 : jh++ / run;
       cntb[blk[k]]++;
       if (c->type != 0) boxb[blk[k]] = 1;
       if (fng[k] >= 0) fb[fng[k]][blk[k]] = 1;
     }
     int nB = 0, nX = 0, nF[5];
-    for (int b = 0; b < 6; b++) nB += cntb[b] > 0;
-    for (int b = 0; b < 7; b++) nX += boxb[b];
-    for (int f = 0; f < 5; f++) { nF[f] = 0; for (int b = 0; b < 7; b++) nF[f] += fb[f][b]; if (nF[f] < 1) nF[f] = 1; }
+    for (int b = 0; b < 12; b++) nB += cntb[b] > 0;
+    for (int b = 0; b < 13; b++) nX += boxb[b];
+    for (int f = 0; f < 5; f++) { nF[f] = 0; for (int b = 0; b < 13; b++) nF[f] += fb[f][b]; if (nF[f] < 1) nF[f] = 1; }
     if (nB < 1) nB = 1;
     if (nX < 1) nX = 1;
     /* T = [I; -G], G_f = Fhat_f^-1 C_f (Mh holds the Cholesky factor by now: take the blocks from M + the diagonal terms) */
@@ -639,7 +640,7 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     for (int it = 0; it < cfg->num_position_iterations; it++) {
       real dsum[NV];
       memset(dsum, 0, sizeof dsum);
-      for (int b = 0; b < 7; b++) {
+      for (int b = 0; b < 13; b++) {
         if (!cntb[b]) continue;
         real vb[NV], db[NV];
         memcpy(vb, v, sizeof vb);
