@@ -7,6 +7,7 @@ import ctypes as C
 
 NJ, NBASE, NFINGER, NFJ, NACT = 26, 6, 5, 4, 18
 NSITE, NCAP, NFSLOT, KMAX = 11, 18, 17, 24
+NWKEY = 88      # DEXSIM_NWKEY: warm-start cache slots per env
 FSLOT_PALM, FSLOT_BOX = 15, 16
 NRESET_SAMPLES = 29
 MAX_OBS_SEG = 40

@@ -58,7 +58,7 @@ for wv in range(7):
     if wv == 0:   # inside pass 2 of the general path's sweeps: waves 0 and 5
         for w, off in ((0, 56), (5, 61)):
             ss = np.median(np.array([[crow[off + k, e] for k in range(5)] for e in lanes]), axis=0)
-            print(f"  wave {w}: phase 3 starts at {int(ss[2])}, first contact's rows built at {int(ss[3])}; sweep 2 starts at {int(ss[0])}, block pass done +{int(ss[1]-ss[0])}, exchange done +{int(ss[4]-ss[1])}")
+            print(f"  wave {w}, sweep 2: starts at {int(ss[0])}, item done +{int(ss[1]-ss[0])}, barrier passed +{int(ss[2]-ss[1])}, reduction done +{int(ss[3]-ss[2])}, second barrier passed +{int(ss[4]-ss[3])}")
     if wv == 0:   # the launch ends with its slowest workgroup
         slow = st[np.argmax(st[:, 6])]
         print("wave 0, slowest workgroup: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, slow)))

@@ -24,6 +24,14 @@ class HipBackend:
     def get(self, name):
         return self.core.field(name).detach().cpu().numpy().astype(np.float64)
 
+    def warm_cache(self):
+        """The contact solver's warm-start cache in the oracle's terms: (wlam [88 x 3][N], wtag [88][N], wgen [N]).  The arena keeps
+        one float4 per cache slot and env, [slot][env][4] = impulses + the tag's integer bits."""
+        q = self.core.field("wlam").detach().cpu().numpy().reshape(-1).reshape(_abi.NWKEY, -1, 4)
+        lam = np.ascontiguousarray(q[:, :, :3].transpose(0, 2, 1)).reshape(_abi.NWKEY * 3, -1).astype(np.float64)
+        tag = np.ascontiguousarray(q[:, :, 3]).view(np.int32).astype(np.int64)
+        return lam, tag, self.core.field("wgen").detach().cpu().numpy()[0].astype(np.int64)
+
     def obs_buf(self):
         return self.core.obs_buf.detach().cpu().numpy()
 

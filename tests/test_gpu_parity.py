@@ -189,6 +189,17 @@ def test_free_running_steps_match_oracle():
     assert np.percentile(errs, 99) < 5e-3
     assert mism <= 2
     assert o.get("reset_count").sum() > n                    # resets (timeouts at 24) really happened
+    # the contact solver's warm-start cache went through the same life on both sides: one generation per sub-step and reset,
+    # the same slots valid (tag = 8 * generation [+ corner]), the same impulses in them
+    lam_h, tag_h, gen_h = hb.warm_cache()
+    lam_o, tag_o, gen_o = o.get("wlam"), o.get("wtag").astype(np.int64), o.get("wgen")[0].astype(np.int64)
+    assert (gen_h == gen_o).all() and gen_o.min() >= 30 * 4
+    valid_o, valid_h = (tag_o >> 3) == gen_o, (tag_h >> 3) == gen_h
+    agree = (valid_o == valid_h).all(axis=0)
+    assert agree.mean() > 0.97                               # (an env whose contact set differs has diverged: counted above)
+    sel = np.repeat(valid_o & valid_h, 3, axis=0) & agree
+    assert sel.sum() > 3 * 4 * n // 2                        # the resting boxes' ground contacts, at least
+    assert np.percentile(np.abs(lam_h - lam_o)[sel], 99) < 1e-4
 
 
 def test_body_states_and_indexed_setters():
