@@ -105,7 +105,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("DEXSIM_BENCH_LAUNCH_PROBE"):     # tests/test_bench_launch.py: the launch logic without a GPU
-        print(f"probe rank {rank} local_rank {local_rank} world {world} master {os.environ.get('MASTER_ADDR')}", flush=True)
+        # one write() per rank: two ranks printing through buffered streams can interleave inside a line
+        os.write(1, f"probe rank {rank} local_rank {local_rank} world {world} master {os.environ.get('MASTER_ADDR')}\n".encode())
         sys.exit(0)
 
     import torch

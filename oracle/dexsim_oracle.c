@@ -609,7 +609,7 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     real Tm[NJ][6];
     memset(Tm, 0, sizeof Tm);
     for (int i = 0; i < 6; i++) Tm[i][i] = 1;
-    for (int f = 0; f < 5; f++) {
+    for (int f = 0; f < 5 && nhand > 0; f++) {   /* (no hand contact: no row touches the hand, T is not needed) */
       real F[16], Cc[4][6];
       for (int i = 0; i < 4; i++) {
         int gi = 6 + 4 * f + i;
@@ -627,7 +627,8 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     /* response of a row inside its block: Y = T Y_B + P (P: the finger's own part) -> Ys = nB T Y_B + nF P, box part x nX */
     static __thread real Ys[KMAX * 3][NV];
     for (int row = 0; row < 3 * K; row++) {
-      for (int i = 0; i < NJ; i++) {
+      if (e->contact[row / 3].type == 2) for (int i = 0; i < NJ; i++) Ys[row][i] = 0;   /* box/ground rows: no hand part */
+      else for (int i = 0; i < NJ; i++) {
         real t = 0;
         for (int j = 0; j < 6; j++) t += Tm[i][j] * Y[row][j];
         Ys[row][i] = i < 6 ? (real)nB * Y[row][i] : (real)nB * t + (real)nF[(i - 6) / 4] * (Y[row][i] - t);
