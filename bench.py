@@ -245,7 +245,7 @@ def main():
             "config": {"workload": (f"{args.task} num_envs={N}/GPU" + (" (BASELINE configs[2]; configs[3] when n_gpus>1)"
                                     if args.task == "BlindGrasping" and N == 4096 and not args.dr else "")),
                        "control_mode": args.control_mode or "task default",
-                       "num_envs_per_gpu": N, "sim_dt": 0.01, "substeps": 4, "pgs_iterations": 16,
+                       "num_envs_per_gpu": N, "sim_dt": 0.01, "substeps": 4, "pgs_iterations": 16, "contact_solver": "warm-started block-parallel PGS with mass splitting (oracle/dexsim_oracle.c)",
                        "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
                        "rollout_gather_mode": args.gather if world > 1 else None,
                        "domain_randomisation": bool(args.dr)},

@@ -737,10 +737,10 @@ def test_level2_gym_shim_matches_fused_step():
 
 def test_saturated_contact_list_matches_oracle():
     """The whole contact list in use: hands lowered until fingers and palm lie on box and ground -- every env reaches
-    DEXSIM_KMAX = 24 contacts (4 box/ground + 20 hand contacts in priority order, the rest truncated), i.e. hand slots
-    beyond the LDS row slots (rows streamed from the arena) and list entries beyond the 16 LDS header / impulse slots
-    (kept in the sweeping wave's registers).  Contact lists must be identical, the state after a full physics step within
-    the teacher-forced tolerances."""
+    DEXSIM_KMAX = 24 contacts (4 box/ground + 20 hand contacts in priority order, the rest truncated): every env's solver
+    blocks are pairs of contacts and a workgroup has 768 work items, twice its item lanes (the generic variant of the sweeps,
+    two rounds per pass).  Contact lists must be identical, the state after a full physics step within the teacher-forced
+    tolerances."""
     from oracle.oracle import Oracle
     from tests.hip_backend import HipBackend
     from dexrobot_isaac_amd import _abi
@@ -774,6 +774,51 @@ def test_saturated_contact_list_matches_oracle():
     np.testing.assert_allclose(hb.get("cforce"), o.get("cforce"), atol=0.5, rtol=5e-2)
     # ... and three more full physics steps stay finite and in agreement on the list sizes
     for _ in range(3):
+        o.physics_step()
+        hb.physics_step()
+    assert np.isfinite(hb.get("q")).all() and np.abs(hb.get("q") - o.get("q")).max() < 5e-3
+
+
+@pytest.mark.parametrize("z", [-0.292, -0.30, -0.32], ids=["single-contact blocks, > 384 items", "some lanes with pairs", "mostly pairs"])
+def test_generic_sweep_variants_match_oracle(z):
+    """Between the common case (one contact per item lane, resident rows) and the saturated list: hands low enough for 8-14
+    hand contacts per env, so that a workgroup has more work items than item lanes (384) and lanes with single-contact blocks
+    sit next to lanes whose blocks are pairs.  One sub-step from identical state, then two free physics steps."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 128
+    sc, model = _mk("BlindGrasping", n)
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms), HipBackend(sc, ms)
+    rng = np.random.default_rng(2)
+    q = np.zeros((26, n))
+    q[2] = z + rng.uniform(-0.004, 0.004, n)
+    q[3:6] = rng.uniform(-0.1, 0.1, (3, n))
+    q[6:] = rng.uniform(0, 0.3, (20, n))
+    st = dict(q=q, qd=0 * q, targets=q, box_pos=np.array([[0.0], [0.0], [0.0255]]) + 0 * q[:3],
+              box_quat=np.array([[0.0], [0.0], [0.0], [1.0]]) + 0 * q[:4], box_lin=0 * q[:3], box_ang=0 * q[:3])
+    for k, v in st.items():
+        o.set(k, v)
+        hb.set(k, v)
+    o.substep(last=True)
+    hb.substep(last=True)
+    nc_o, nc_h = o.get("ncontact")[0], hb.get("ncontact")[0]
+    assert (nc_o == nc_h).all()
+    nh = np.array([(o.contacts(e)[:, 8] != 2).sum() for e in range(n)])
+    items = np.where(nh > 12, (nh + 1) // 2, nh).reshape(-1, 64).sum(1)          # solver blocks per workgroup
+    assert items.max() > 384                                                      # more items than item lanes: rounds
+    if z > -0.295:
+        assert (nh <= 12).all()                                                   # no pairs anywhere: rounds of single contacts
+    if z < -0.31:
+        assert (nh > 12).mean() > 0.5
+    np.testing.assert_allclose(hb.get("q"), o.get("q"), atol=2e-4)
+    np.testing.assert_allclose(hb.get("qd"), o.get("qd"), atol=1e-2, rtol=5e-3)
+    np.testing.assert_allclose(hb.get("box_pos"), o.get("box_pos"), atol=2e-4)
+    np.testing.assert_allclose(hb.get("cforce"), o.get("cforce"), atol=0.5, rtol=5e-2)
+    lam_h, tag_h, gen_h = hb.warm_cache()
+    tag_o, gen_o = o.get("wtag").astype(np.int64), o.get("wgen")[0].astype(np.int64)
+    assert (gen_h == gen_o).all() and (((tag_h >> 3) == gen_h) == ((tag_o >> 3) == gen_o)).all()   # the same cache slots written
+    for _ in range(2):
         o.physics_step()
         hb.physics_step()
     assert np.isfinite(hb.get("q")).all() and np.abs(hb.get("q") - o.get("q")).max() < 5e-3

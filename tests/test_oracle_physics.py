@@ -200,3 +200,32 @@ def test_narrowphase_properties_of_the_round2_manifold():
             assert (mine[:, 8] == 1).sum() <= 2 and (mine[:, 8] == 0).sum() <= 2
             seen_two += int((mine[:, 8] == 1).sum() == 2)
     assert total > 6 * n and seen_two > 0                                # the sample has line contacts (two points on one capsule)
+
+
+def test_warm_started_block_solver_reaches_the_converged_solution():
+    """Round 2's contact solver (warm start + block-parallel projected Gauss-Seidel with mass splitting, 16 sweeps per
+    sub-step) against the same solver run to convergence (200 sweeps): one finger pressing the box onto the ground -- a
+    stack, the hard case for a Jacobi-type scheme.  Once the contact persists the 16-sweep solver carries the converged
+    impulses from sub-step to sub-step: same contact force, box at rest.  (Round 1's cold-started sequential solver
+    left 26 N of these 30 N and a box creeping at 1 cm/s.)  The warm-start cache itself: one generation per sub-step, one
+    valid slot per contact."""
+    def run(iters):
+        cfg = default_cfg("BlindGrasping")
+        cfg["env"]["numEnvs"] = 1
+        sc, model = build_sim_config(cfg)
+        sc.num_position_iterations = iters
+        o = Oracle(sc, model.to_struct(), f64=True)
+        tg = np.zeros((26, 1))
+        for _ in range(300):
+            tg[2] = max(tg[2] - 0.001, -0.2445)
+            o.set("targets", tg)
+            o.physics_step()
+        cf = o.get("cforce")[:, 0].reshape(17, 3)
+        return o, np.linalg.norm(cf[8]), np.abs(o.get("box_lin")).max(), np.abs(o.get("box_ang")).max()
+    o16, f16, v16, w16 = run(16)
+    _, f200, v200, _ = run(200)
+    assert 20.0 < f200 < 40.0 and v200 < 1e-8                   # the converged solution: ~30 N on the middle fingertip, box at rest
+    assert abs(f16 - f200) < 1e-3 * f200 and v16 < 1e-8 and w16 < 1e-8
+    gen, tag, nc = int(o16.get("wgen")[0, 0]), o16.get("wtag")[:, 0].astype(int), int(o16.get("ncontact")[0, 0])
+    assert gen == 300 * 4 and ((tag >> 3) == gen).sum() == nc    # 4 box/ground slots + the fingertip contact
+    assert nc == 5 and (tag[80:84] >> 3 == gen).all() and sorted(tag[80:84] & 7) == [0, 1, 2, 3]   # bottom corners of the box
