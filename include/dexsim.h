@@ -37,7 +37,8 @@ extern "C" {
 #define DEXSIM_FSLOT_PALM 15
 #define DEXSIM_FSLOT_BOX  16
 #define DEXSIM_KMAX      24   /* max active contacts per env per sub-step (<= 4 box/ground + hand contacts in priority order) */
-#define DEXSIM_NWKEY 88      /* warm-start cache keys: (capsule * 2 + type) * 2 + sample for hand contacts (< 72), 80 + corner for box/ground */
+#define DEXSIM_NWKEY 88      /* warm-start cache slots of the contact solver: (capsule * 2 + type) * 2 + sample for hand contacts (< 72),
+                                80 + list slot for the (<= 4) box/ground contacts (their tag carries the box corner) */
 #define DEXSIM_NRESET_SAMPLES 29 /* rand draws of one reset (blind_grasping_task.py:449-547)            */
 #define DEXSIM_MAX_OBS_SEG 40
 
@@ -334,7 +335,9 @@ int dexsim_reset(dexsim_t h, void* stream);
 int dexsim_refresh_body_states(dexsim_t h, void* stream);
 
 /* gym.set_dof_state_tensor_indexed / set_actor_root_state_tensor_indexed
- * (physics_manager.py:146-151, reset_manager.py:153-158): ingest the AoS API tensors for k envs. */
+ * (physics_manager.py:146-151, reset_manager.py:153-158): ingest the AoS API tensors for k envs.
+ * (The contact solver's warm-start cache -- arena field `wlam`, generation `wgen` -- is invalidated by resets, not by these
+ * setters: after a teleport a stale entry is only the starting guess of the first sub-step's solve.) */
 int dexsim_set_dof_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream);
 int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream);
 
