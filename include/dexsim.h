@@ -37,6 +37,8 @@ extern "C" {
 #define DEXSIM_FSLOT_PALM 15
 #define DEXSIM_FSLOT_BOX  16
 #define DEXSIM_KMAX      24   /* max active contacts per env per sub-step (<= 4 box/ground + hand contacts in priority order) */
+#define DEXSIM_BISECT_ITERS 10 /* capsule / box narrowphase: bisection steps for the point of the capsule axis nearest to the box
+                                (2^-10 of the axis, ~30 um; the gap is stationary there: its error is second order) */
 #define DEXSIM_NWKEY 88      /* warm-start cache slots of the contact solver: (capsule * 2 + type) * 2 + sample for hand contacts (< 72),
                                 80 + list slot for the (<= 4) box/ground contacts (their tag carries the box corner) */
 #define DEXSIM_NRESET_SAMPLES 29 /* rand draws of one reset (blind_grasping_task.py:449-547)            */

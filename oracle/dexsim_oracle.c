@@ -468,7 +468,7 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
       real reach = (real)0.5 * v3norm(d) + r + (real)1.7320508 * hb[0] + co;
       if (v3dot(mid, mid) < reach * reach) {
         real lo = 0, hi = 1;
-        for (int it = 0; it < 16; it++) {
+        for (int it = 0; it < DEXSIM_BISECT_ITERS; it++) {
           real mdl = (real)0.5 * (lo + hi);
           if (seg_box_dfdt(a, d, mdl, hb) > 0) hi = mdl; else lo = mdl;
         }

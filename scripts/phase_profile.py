@@ -55,7 +55,11 @@ for wv in range(7):
     st = np.array([[crow[wv * 8 + k, e] for k in range(8)] for e in lanes])
     med = np.median(st, axis=0)
     print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))
-    if wv == 0:   # inside pass 2 of the general path's sweeps: waves 0 and 5
+    if wv == 0 and "DBG_PH2" in os.environ.get("DEXSIM_EXTRA_DEFS", ""):   # inside phase 2 of the general path: waves 1 and 5
+        for w, off in ((1, 56), (5, 60)):
+            ss = np.median(np.array([[crow[off + k, e] for k in range(3)] for e in lanes]), axis=0)
+            print(f"  wave {w}, phase 2: narrowphase done at {int(ss[0])}, barrier passed {int(ss[1])}, appended {int(ss[2])}")
+    elif wv == 0:   # inside pass 2 of the general path's sweeps: waves 0 and 5
         for w, off in ((0, 56), (5, 61)):
             ss = np.median(np.array([[crow[off + k, e] for k in range(5)] for e in lanes]), axis=0)
             print(f"  wave {w}, sweep 2: starts at {int(ss[0])}, item done +{int(ss[1]-ss[0])}, barrier passed +{int(ss[2]-ss[1])}, reduction done +{int(ss[3]-ss[2])}, second barrier passed +{int(ss[4]-ss[3])}")

@@ -644,7 +644,8 @@ def test_hip_error_is_a_small_multiple_of_fp32_roundoff():
     print("\nfield: p99.9 |f32-f64|, p99.9 |HIP-f64|, max |f32-f64|, max |HIP-f64|")
     for f, r in report.items():
         print(f"  {f:8s} {r[0]:.3e} {r[1]:.3e} {r[2]:.3e} {r[3]:.3e}")
-    c = 2.5     # measured round 2: 1.0-1.5 for every field (profiles/round2_*/README.md)
+    c = 3.0     # measured: 1.0-1.5 with round 1's sequential solver, 1.2-2.7 with round 2's block solver (the box twist goes
+                # through per-block copies and a sum over the blocks: profiles/round2_e/README.md)
     for f, r in report.items():
         assert r[1] <= c * r[0] + 1e-7, (f, r)
         assert r[3] <= c * r[2] + 1e-6, (f, r)
