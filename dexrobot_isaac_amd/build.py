@@ -28,7 +28,12 @@ def build_lib(force=False, verbose=False):
     # -fno-slp-vectorize: the auto-vectoriser's v_pk_* pairs cost more v_mov shuffles and wait states than they
     # save here (13.8k -> 13.4k instructions, scratch 112 -> 48 B in k_substep); packed FP32 is written by hand
     # (f2) where it pays.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17",
+    # -fno-hip-fp32-correctly-rounded-divide-sqrt: fp32 `/` and sqrtf as the <= 2.5 ulp sequences (v_rcp / v_rsq + one
+    # Newton step) instead of the correctly rounded ones (v_div_scale / v_div_fmas / v_div_fixup, ~10 instructions each): the
+    # step kernel has ~60 divisions per wave and sub-step and is VALU-issue bound on the SIMDs that carry two finger waves
+    # (75.4 -> 69.9 us per control step).  Still fp32 arithmetic; every parity test (golden vectors of the reference at 2e-5 /
+    # 2e-6, oracle at the fp64-derived tolerance) holds unchanged -- 2.5 ulp is 3e-7 relative.
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-std=c++17",
            "-o", LIB, os.path.join(CSRC, "dexsim.hip")]
     if verbose:
         print(" ".join(cmd))
