@@ -55,6 +55,9 @@ for wv in range(7):
     st = np.array([[crow[wv * 8 + k, e] for k in range(8)] for e in lanes])
     med = np.median(st, axis=0)
     print(f"wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, med)))
+    if wv == 0 and "DBG_SCHUR" in os.environ.get("DEXSIM_EXTRA_DEFS", ""):   # inside wave 0's Schur phase
+        ss = np.median(np.array([[crow[56 + k, e] for k in range(6)] for e in lanes]), axis=0)
+        print("  wave 0, Schur phase: start %d, composite sum %d, own rows %d, tokens seen %d, S / tau_B complete %d, solved %d" % tuple(int(v) for v in ss))
     if wv == 0 and "DBG_PH2" in os.environ.get("DEXSIM_EXTRA_DEFS", ""):   # inside phase 2 of the general path: waves 1 and 5
         for w, off in ((1, 56), (5, 60)):
             ss = np.median(np.array([[crow[off + k, e] for k in range(3)] for e in lanes]), axis=0)
