@@ -137,6 +137,35 @@ def test_broadphase_regimes_match_oracle(z_range):
     np.testing.assert_allclose(hb.get("site_pose"), o.get("site_pose"), atol=5e-4)
 
 
+def test_split_schur_phase_matches_the_one_wave_version():
+    """Hand clear of box and ground in every workgroup: the fused sub-step splits the Schur phase over four waves (three
+    helpers post their shares of S, the bias and the G^T tau sum through LDS behind tokens) while the staged k_dynamics
+    runs it on one wave.  Same expressions, same accumulation order -- the two launches still differ in where the compiler
+    contracts multiply-adds, so the comparison is to a few ulp (2e-6 of the largest velocity, 1e-7 on positions), which a
+    wrong or stale hand-over word would miss by orders of magnitude; padded lanes included."""
+    from tests.hip_backend import HipBackend
+    n = 200                                          # 4 workgroups, the last one padded
+    sc, model = _mk("BlindGrasping", n)
+    ms = model.to_struct()
+    a, b = HipBackend(sc, ms, fused=True), HipBackend(sc, ms, fused=False)
+    rng = np.random.default_rng(23)
+    st = _random_state(rng, model, n, near_box=False)
+    st["q"][2] = rng.uniform(-0.05, 0.2, n)
+    st["q"] = np.clip(st["q"], model.lo[:, None] + 1e-3, model.hi[:, None] - 1e-3)
+    for k, v in st.items():
+        a.set(k, v)
+        b.set(k, v)
+    for sub in range(3):
+        a.substep(last=True)
+        b.substep(last=True)
+        assert a.get("ncontact").max() <= 4          # box/ground contacts only: the split path ran
+        x, y = a.get("qd"), b.get("qd")
+        assert np.abs(x - y).max() <= 2e-6 * max(1.0, np.abs(y).max()), f"qd differs after sub-step {sub}: {np.abs(x - y).max():.3e}"
+        np.testing.assert_allclose(a.get("q"), b.get("q"), atol=1e-7, rtol=0)
+        for k in ("q", "qd"):                        # both continue from the same state: no drift accumulates in the comparison
+            a.set(k, b.get(k))
+
+
 def test_contact_manifold_matches_oracle():
     """Narrowphase only: identical contact lists (type, capsule, order) and geometry within 1e-6."""
     from oracle.oracle import Oracle
