@@ -92,3 +92,19 @@ for b in range(4):
     for wv in (0, 4, 5, 6):
         st = np.array([[crow[64 * (b + 1) + wv * 8 + k, e] for k in range(7 if b == 3 else 6)] for e in lanes])
         print(f"k_physics4 body {b} wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, np.median(st, axis=0))))
+
+# what a stamp tick is worth: the same launch timed with events (isolated, then 20 back to back), next to the sum of the four
+# bodies' stamps of the median workgroup
+tot = 0
+for b in range(4):
+    st = np.array([[crow[64 * (b + 1) + 0 * 8 + k, e] for k in range(7 if b == 3 else 6)] for e in lanes])
+    tot += int(np.median(st, axis=0)[-1])
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); core.run_stage(_abi.STAGE["PHYSICS"]); e1.record(); torch.cuda.synchronize()
+one = e0.elapsed_time(e1) * 1e3
+e0.record()
+for _ in range(20):
+    core.run_stage(_abi.STAGE["PHYSICS"])
+e1.record(); torch.cuda.synchronize()
+many = e0.elapsed_time(e1) * 1e3 / 20
+print(f"k_physics4 (profile build): {tot} stamp ticks over the four bodies (wave 0, median workgroup); one launch {one:.1f} us, 20 back to back {many:.1f} us each -> {tot / many / 1e3:.2f} ticks per ns")
