@@ -15,7 +15,7 @@ from dexrobot_isaac_amd.build import CSRC  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "libdexsim_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-std=c++17", "-DDEXSIM_PROFILE_PHASES"] +
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared", "-std=c++17", "-DDEXSIM_PROFILE_PHASES"] +
                       os.environ.get("DEXSIM_EXTRA_DEFS", "").split() + [
                        "-o", out, os.path.join(CSRC, "dexsim.hip")], cwd=CSRC)   # DEXSIM_EXTRA_DEFS: experiment switches (-DEXP_...)
 _lib.LIB_PATH = out
