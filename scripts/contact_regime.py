@@ -44,7 +44,7 @@ for label, z in regimes:
     nc = core.field("ncontact").float()
     print(f"{label}: {e0.elapsed_time(e1) * 10:.1f} us per physics step (4 sub-steps), contacts/env mean {nc.mean().item():.2f} "
           f"max {int(nc.max().item())}")
-    if z == -0.40:
+    if z < 0:
         # the 100 timed steps above follow the teleport by only 20 steps (round 1's protocol, kept for comparison): the contact
         # lists are still settling.  The settled state: 100 more steps in blocks of 20, events around each block, no syncs between
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
