@@ -10,18 +10,29 @@ LIB = os.path.join(HERE, "libdexsim.so")
 SOURCES = ["dexsim.hip", "dexsim_device.h", "dexsim_physics.hip.inc", "dexsim_l2.hip.inc"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+DEBUG_SPIN_LIB = os.path.join(HERE, "libdexsim_dbgspin.so")
+
+
+def _stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "dexsim.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False):
+def build_debug_spin(force=False, bound=2000000):
+    """Diagnostic twin of the library with every LDS token wait bounded (-DDEXSIM_DEBUG_SPIN=<polls>, see
+    dexsim_physics.hip.inc): a sequencing bug shows up as a recorded word in the counters block instead of a hung GPU.
+    Loaded only by tests/ (DEXSIM_LIB_PATH); the product never uses it."""
+    return build_lib(force=force, defs=(f"-DDEXSIM_DEBUG_SPIN={int(bound)}",), out=DEBUG_SPIN_LIB)
+
+
+def build_lib(force=False, verbose=False, defs=(), out=None):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Returns the path of the library."""
-    if not force and not _stale():
-        return LIB
+    lib = out or LIB
+    if not force and not _stale(lib):
+        return lib
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libdexsim.so cannot be built on this machine")
@@ -37,12 +48,12 @@ def build_lib(force=False, verbose=False):
     # their SIMD, so the scheduler should interleave independent chains rather than minimise register pressure: same VGPR
     # counts, still no spills / scratch, 61.3 -> 62.2 M env-steps/s (contact-rich regime 187 -> 189 us: within 1 %).
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared", "-std=c++17",
-           "-o", LIB, os.path.join(CSRC, "dexsim.hip")]
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared", "-std=c++17", *defs,
+           "-o", lib, os.path.join(CSRC, "dexsim.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

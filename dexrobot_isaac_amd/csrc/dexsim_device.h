@@ -90,6 +90,7 @@ struct DevParams {
 #define CNT_CONTACTS 16   /* [2], by stamp parity: sum of active contacts of the control step's main physics step (last
                              sub-step); word stamp&1 is accumulated and read by the step, the other word is cleared for the next */
 #define CNT_HAND_CONTACTS 18 /* [2], same scheme: the hand/box and hand/ground contacts among them */
+#define CNT_SPIN_TIMEOUT 20  /* diagnostic build -DDEXSIM_DEBUG_SPIN only: (site << 24 | seq) of an LDS token wait that ran into its bound */
 #define CNT_PHYS_STEPS 13
 #define CNT_CONSECUTIVE 14 /* persistent */
 #define CNT_RC_FIRST 15    /* persistent: RewardCalculator lazy prev-state init pending */

@@ -41,6 +41,10 @@ extern "C" {
                                 (2^-10 of the axis, ~30 um; the gap is stationary there: its error is second order) */
 #define DEXSIM_NWKEY 88      /* warm-start cache slots of the contact solver: (capsule * 2 + type) * 2 + sample for hand contacts (< 72),
                                 80 + list slot for the (<= 4) box/ground contacts (their tag carries the box corner) */
+/* the warm-start generation of an env advances once per sub-step and once per reset; it wraps at 2^27 so that the cache tags
+   8 * generation + corner stay below 2^30 in signed 32-bit arithmetic for any run length (a generation is only ever compared
+   with the one before it: a tag can falsely match only if its slot sat unwritten for exactly 2^27 generations) */
+#define DEXSIM_WGEN_NEXT(g) (((g) + 1) & 0x07ffffff)
 #define DEXSIM_NRESET_SAMPLES 29 /* rand draws of one reset (blind_grasping_task.py:449-547)            */
 #define DEXSIM_MAX_OBS_SEG 40
 

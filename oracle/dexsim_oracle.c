@@ -667,7 +667,7 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     }
   }
   {
-    e->wgen++;
+    e->wgen = DEXSIM_WGEN_NEXT(e->wgen);
     for (int k = 0; k < K; k++) {
       const OrcContact* c = &e->contact[k];
       int key = c->type == 2 ? 80 + k : c->key;
@@ -1107,7 +1107,7 @@ static void reset_env(const Oracle* o, OrcEnv* e, int idx) {
     for (int i = 0; i < 20; i++) e->q[6 + i] = u[9 + i] * (i == 0 ? c->thumb_rotation_range : c->other_finger_range);
   }
   e->reset_count++;
-  e->wgen++;   /* the warm-start cache does not survive a teleport */
+  e->wgen = DEXSIM_WGEN_NEXT(e->wgen);   /* the warm-start cache does not survive a teleport */
   /* ActionProcessor.reset_targets (action_processor.py:524-568) */
   for (int i = 0; i < NJ; i++) e->targets[i] = e->q[i];
   extract_active_targets(e->q, e->active_prev_targets);

@@ -909,3 +909,73 @@ def test_general_contact_path_is_bitwise_reproducible():
     assert outs[0][-1].float().mean() > 6 and outs[0][-1].max() > 8          # hands really rest on box and ground
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_debug_spin_build_never_hits_its_bound():
+    """The LDS token waits of the sub-step kernel (box wave <- broadphase verdicts, Schur wave <- its helpers) are unbounded in
+    the product build.  Its diagnostic twin (-DDEXSIM_DEBUG_SPIN, dexrobot_isaac_amd/build.py::build_debug_spin) bounds every
+    wait and records a word in the counters block when one runs out: driven through the hand-clear and the general contact path
+    it must record nothing and produce bit-identical results to the product build."""
+    import json
+    import subprocess
+    import sys
+    from dexrobot_isaac_amd.build import DEBUG_SPIN_LIB, LIB
+    assert os.path.exists(DEBUG_SPIN_LIB), "build it with __graft_entry__.build() / build_debug_spin()"
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "debug_spin_child.py")
+    res = {}
+    for name, lib in (("product", LIB), ("debug", DEBUG_SPIN_LIB)):
+        out = subprocess.run([sys.executable, child], env={**os.environ, "DEXSIM_LIB_PATH": lib}, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["debug"]["spin_word"] == 0, f"a token wait ran into its bound: site/seq word {res['debug']['spin_word']:#x}"
+    assert res["debug"]["hand_contacts"] > 4.0          # the general contact path really ran
+    assert res["debug"]["digest"] == res["product"]["digest"]
+
+
+@pytest.mark.gpu
+def test_warm_start_generation_wrap_on_the_hip_path():
+    """ADVICE round 2 (GPU half; CPU half: test_oracle_physics.py::test_warm_start_generation_wraps_...): two instances in the
+    same contact-rich state, one with its warm-start generation moved right below the 2^27 wrap.  Across the wrap the
+    kernels must go through bit-identical states (the cache keeps warming, box/ground and hand slots alike) and every tag
+    stays a small positive integer."""
+    import torch
+    from dexrobot_isaac_amd import _abi
+    from dexrobot_isaac_amd.core import DexSimCore
+    n, wrap = 256, 1 << 27
+    sc, model = _mk("BlindGrasping", n)
+    outs = []
+    for gen0 in (1000, wrap - 30):
+        core = DexSimCore(sc, model.to_struct(), "cuda:0")
+        core.reset()
+        g = torch.Generator(device="cuda:0").manual_seed(3)
+        q = core.field("q")
+        q.zero_()
+        q[2] = -0.40
+        q[6:] = 0.3 * torch.rand(20, n, device="cuda:0", generator=g)
+        core.field("qd").zero_()
+        core.field("targets").copy_(q)
+        for _ in range(60):
+            core.physics_step(False)
+        # move every env's generation to gen0; valid tags (8 * gen + corner) move with it, stale ones are dropped
+        off, rows, _ = core.fields["wlam"]
+        quad = core._arena_i32[off: off + rows * core.NS].view(_abi.NWKEY, core.NS, 4)
+        gen = core.field("wgen")[0].clone()
+        tag = quad[:, :n, 3]
+        valid = (tag >> 3) == gen[None, :]
+        quad[:, :n, 3] = torch.where(valid, 8 * gen0 + (tag & 7), torch.zeros_like(tag))
+        core.field("wgen").fill_(gen0)
+        nvalid0 = int(valid.sum().item())
+        for _ in range(20):                       # 80 generations: the second instance crosses the wrap
+            core.physics_step(False)
+        torch.cuda.synchronize()
+        tag = quad[:, :n, 3].clone()
+        gen = core.field("wgen")[0]
+        assert int(gen[0].item()) == (gen0 + 80) % wrap and bool((gen == gen[0]).all())
+        assert int(tag.min().item()) >= 0 and int(tag.max().item()) < (1 << 30)
+        nvalid = int(((tag >> 3) == gen[None, :]).sum().item())
+        assert nvalid == int(core.field("ncontact").sum().item()) and nvalid0 > 4 * n     # one valid slot per contact, hand contacts among them
+        outs.append([core.field(f).clone() for f in ("q", "qd", "box_pos", "box_quat", "box_lin", "box_ang", "cforce", "ncontact")]
+                    + [quad[:, :n, :3].clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -229,3 +229,31 @@ def test_warm_started_block_solver_reaches_the_converged_solution():
     gen, tag, nc = int(o16.get("wgen")[0, 0]), o16.get("wtag")[:, 0].astype(int), int(o16.get("ncontact")[0, 0])
     assert gen == 300 * 4 and ((tag >> 3) == gen).sum() == nc    # 4 box/ground slots + the fingertip contact
     assert nc == 5 and (tag[80:84] >> 3 == gen).all() and sorted(tag[80:84] & 7) == [0, 1, 2, 3]   # bottom corners of the box
+
+
+def test_warm_start_generation_wraps_without_losing_the_cache():
+    """the warm-start generation only ever grows (one per sub-step, one per reset) and the cache tags are
+    8 * generation + corner in signed 32-bit arithmetic.  It now wraps at 2^27 (DEXSIM_WGEN_NEXT): an env whose generation
+    crosses the wrap while a finger presses on the box must go through exactly the same states as one far away from it -- the
+    cache keeps warming across the wrap, and no tag ever leaves the positive int range (UBSan build: make -C oracle asan)."""
+    def run(gen0):
+        o, _, _ = _mk(n=1, f64=True)
+        tg = np.zeros((26, 1))
+        for s in range(300):
+            if s == 260:                         # contact established: move the generation to gen0 (tags move with it)
+                g = int(o.get("wgen")[0, 0])
+                tag = o.get("wtag")[:, 0].astype(np.int64)
+                o.set("wtag", np.where(tag >> 3 == g, 8 * gen0 + (tag & 7), 0).reshape(-1, 1))
+                o.set("wgen", np.array([[gen0]]))
+            tg[2] = max(tg[2] - 0.001, -0.2445)
+            o.set("targets", tg)
+            o.physics_step()
+        return o
+    wrap = 1 << 27
+    a, b = run(1000), run(wrap - 40)             # 40 physics steps x 4 sub-steps = 160 generations: b crosses the wrap
+    assert int(a.get("wgen")[0, 0]) == 1000 + 160 and int(b.get("wgen")[0, 0]) == (wrap - 40 + 160) % wrap == 120
+    for f in ("q", "qd", "box_pos", "box_lin", "cforce", "wlam"):
+        np.testing.assert_array_equal(a.get(f), b.get(f), err_msg=f)
+    tb, gb = b.get("wtag")[:, 0].astype(np.int64), int(b.get("wgen")[0, 0])
+    assert ((tb >> 3) == gb).sum() == int(b.get("ncontact")[0, 0]) == 5 and tb.min() >= 0 and tb.max() < (1 << 30)
+    assert np.linalg.norm(b.get("cforce")[:, 0].reshape(17, 3)[8]) > 20.0      # still the converged ~30 N press
