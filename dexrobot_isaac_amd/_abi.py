@@ -20,6 +20,7 @@ NUM_SUCC, NUM_FAIL = 1, 5
 NUM_MASKS = 3 + NUM_SUCC + NUM_FAIL
 MASK_SUCCESS, MASK_FAILURE, MASK_TIMEOUT, MASK_SUCC_REASON, MASK_FAIL_REASON = 0, 1, 2, 3, 3 + NUM_SUCC
 STAT_WORDS = 64
+STAT_USED = 20
 STAT = dict(SUCC_MEAN=0, FAIL_MEAN=4, SUCCESS_RATE=12, FAILURE_RATE=13, TIMEOUT_RATE=14,
             CONSECUTIVE_SUCCESSES=15, NUM_RESETS=16, PHYSICS_STEPS=17, MEAN_CONTACTS=18, MEAN_HAND_CONTACTS=19)
 
@@ -109,7 +110,7 @@ EXPORTED_SYMBOLS = [
     "dexsim_body_name", "dexsim_create", "dexsim_destroy", "dexsim_bind", "dexsim_init_state",
     "dexsim_process_actions", "dexsim_begin_step", "dexsim_physics_step", "dexsim_post_physics", "dexsim_step",
     "dexsim_reset_idx", "dexsim_reset", "dexsim_refresh_body_states", "dexsim_set_dof_state_indexed",
-    "dexsim_set_root_state_indexed", "dexsim_run_stage", "dexsim_time_stage", "dexsim_step_timing", "dexsim_set_step_sink", "dexsim_set_action_copy", "dexsim_error_string",
+    "dexsim_set_root_state_indexed", "dexsim_run_stage", "dexsim_time_stage", "dexsim_step_timing", "dexsim_set_step_sink", "dexsim_set_stats_sink", "dexsim_set_action_copy", "dexsim_error_string",
     "dexsim_last_error",
 ]
 
@@ -142,6 +143,7 @@ def declare_prototypes(lib):
     lib.dexsim_step_timing.argtypes = [vp, i32, P(f32), P(i32)]
     lib.dexsim_set_step_sink.argtypes = [vp, vp, vp, vp]
     lib.dexsim_set_action_copy.argtypes = [vp, vp]
+    lib.dexsim_set_stats_sink.argtypes = [vp, vp]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name).restype = i32
     lib.dexsim_error_string.argtypes = [i32]

@@ -189,6 +189,13 @@ class DexSimCore:
         check(self.lib.dexsim_set_step_sink(self.h, ptr(obs, torch.float32, (self.N, int(self.cfg.num_obs))),
                                             ptr(rew, torch.float32, (self.N,)), ptr(done, torch.uint8, (self.N,))), "set_step_sink")
 
+    def set_stats_sink(self, dst):
+        """(STAT_WORDS,) f32 row that receives a copy of every step's statistics block (dexsim_set_stats_sink), or None."""
+        if dst is not None:
+            assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.device == self.device and dst.numel() >= _abi.STAT_USED
+        self._sink_stats = dst
+        check(self.lib.dexsim_set_stats_sink(self.h, None if dst is None else C.c_void_p(dst.data_ptr())), "set_stats_sink")
+
     def set_action_copy(self, dst):
         """(N, num_actions) f32 tensor that receives a copy of every step's actions (DexHandBase.actions), or None."""
         if dst is not None:

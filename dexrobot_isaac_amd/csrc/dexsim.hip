@@ -564,6 +564,12 @@ int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done) {
   return DEXSIM_OK;
 }
 
+int dexsim_set_stats_sink(dexsim_t h, float* dst) {
+  if (!h) return fail(DEXSIM_ERR_ARG, "null handle");
+  h->api.sink_stats = dst;   // kernel argument: effective from the next launch
+  return DEXSIM_OK;
+}
+
 int dexsim_set_action_copy(dexsim_t h, float* dst) {
   if (!h) return fail(DEXSIM_ERR_ARG, "null handle");
   h->api.actions_copy = dst;

@@ -143,6 +143,7 @@ enum {
 #define DEXSIM_STAT_PHYSICS_STEPS 17 /* physics steps executed in this control step (1 or 2)   */
 #define DEXSIM_STAT_MEAN_CONTACTS 18 /* mean active contacts/env in the last sub-step of the step's main physics step */
 #define DEXSIM_STAT_MEAN_HAND_CONTACTS 19 /* ... of which hand/box and hand/ground (the rest is box/ground)            */
+#define DEXSIM_STAT_USED  20 /* statistics words in use (the rest of the block is reserved)            */
 #define DEXSIM_STAT_WORDS 64
 
 /* number of hand bodies published in rigid_body_states: 7 base-chain + 30 finger bodies */
@@ -353,6 +354,13 @@ int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, voi
  * the caller's (T, N, ...) rollout tensors -- so that collecting a rollout needs no copy kernels.  Any pointer may be
  * NULL; all NULL switches the sink off.  The pointers are kernel arguments: no device memory is touched by this call. */
 int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done);
+
+/* Statistics sink: the launch that closes a control step (finalize_stats: the cross-env means / rates of
+ * TerminationManager.evaluate, termination_manager.py:160-185, and consecutive successes, :323-339) also copies the first
+ * DEXSIM_STAT_USED words of the statistics block to `dst` -- row t of the caller's (T, DEXSIM_STAT_WORDS) rollout tensor -- so that
+ * envs sharded over ranks can reduce their whole-population statistics with ONE small all-reduce per rollout (rollout.py:
+ * reduce_stats) instead of one per step.  NULL switches it off.  Kernel argument like the step sink. */
+int dexsim_set_stats_sink(dexsim_t h, float* dst);
 
 /* DexHandBase.pre_physics_step keeps `self.actions = actions.clone()` (dexhand_base.py:851).  With a destination set here
  * ((N, num_actions) f32 on the device, or NULL to switch off) the action block writes that copy itself, so the host side

@@ -37,6 +37,8 @@ class OracleCore:
         self.masks = torch.zeros(_abi.NUM_MASKS, N, dtype=torch.bool)
         self._fields = {}
         self._raw = None
+        self._sink = (None, None, None)
+        self._sink_stats = None
         self._sync()
 
     # persistent tensors so that views handed out by DexHandEnv stay valid (updated in place)
@@ -97,15 +99,32 @@ class OracleCore:
         self.orc.post_physics(obs_only)
         self._finish_step()
 
-    def _finish_step(self):
+    def _finish_step(self, sink=False):
         self._sync()
         self.episode_length.copy_(self.episode_step_count)
+        if sink:                               # what the HIP step's flush / closing launch do (dexsim_set_step_sink, dexsim_set_stats_sink)
+            so, sr, sd = self._sink
+            if so is not None:
+                so.copy_(self.obs_buf)
+            if sr is not None:
+                sr.copy_(self.rew_buf)
+            if sd is not None:
+                sd.copy_(self.reset_buf.to(torch.uint8))
+            if self._sink_stats is not None:
+                self._sink_stats[: _abi.STAT_USED].copy_(self.stats[: _abi.STAT_USED])
+
+    def set_step_sink(self, obs=None, rew=None, done=None):
+        self._sink = (obs, rew, done)
+        self._sink_obs = obs
+
+    def set_stats_sink(self, dst):
+        self._sink_stats = dst
 
     def step(self, actions):
         a = actions.detach().cpu().numpy().astype(np.float32)
         self.orc.lib.orc_step(self.orc.h, np.ascontiguousarray(a).ctypes.data)
         # obs/rew/done of the oracle are the pre-reset values of the step, like the reference's returned buffers
-        self._finish_step()
+        self._finish_step(sink=True)
         # episode_length is cloned before... after the resets in the reference (step_processor.py:221-232)
 
     def reset(self):

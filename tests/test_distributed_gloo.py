@@ -89,3 +89,96 @@ def test_single_process_gather_is_identity():
     buf.add(torch.ones(3, 5), torch.ones(3), torch.zeros(3, dtype=torch.bool))
     with pytest.raises(RuntimeError, match="full"):
         buf.add(torch.ones(3, 5), torch.ones(3), torch.zeros(3, dtype=torch.bool))
+
+
+def _sink_worker(rank, world, port, out_dir, mode):
+    """The path bench.py runs on N > 1 GPUs: RolloutBuffer.sink() before every step (the step writes its outputs and its
+    statistics block straight into the slot), gather_async() when the slot is full while the env keeps stepping into the other
+    slot, handles consumed one rollout late."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dexrobot_isaac_amd import _abi, default_cfg, make_env
+    from dexrobot_isaac_amd.rollout import RolloutBuffer
+    from oracle.py_backend import OracleCore
+    N, T, ROLLOUTS = 6, 4, 3
+    cfg = default_cfg("BlindGrasping")
+    cfg["train"]["seed"] = 42 + rank
+    cfg["env"]["episodeLength"] = 4 + rank                   # rank 0 times out every 3 steps, rank 1 every 4: the ranks' rates differ
+    env = make_env("BlindGrasping", N, "cpu", "cpu", 0, cfg=cfg, _core_factory=OracleCore)
+    env.reset()
+    core = env._core
+    buf = RolloutBuffer(T, N, env.num_observations, "cpu", mode=mode)
+    g = torch.Generator().manual_seed(1234 + rank)
+    local, local_stats, pending, results = [], [], [], []
+    for step in range(ROLLOUTS * T):
+        buf.sink(core)                                       # BEFORE the step, as in bench.py
+        obs, rew, done, _ = env.step(2 * torch.rand(N, 18, generator=g) - 1)
+        local.append((obs.clone(), rew.clone(), done.clone()))
+        local_stats.append(core.stats.clone())
+        if buf.full():
+            pending.append(buf.gather_async())               # collectives in flight, next rollout fills the other slot
+            if len(pending) > 1:
+                h = pending.pop(0)
+                results.append((h(), h.stats()))
+    while pending:
+        h = pending.pop(0)
+        results.append((h(), h.stats()))
+    assert len(results) == ROLLOUTS
+    S = _abi.STAT
+    mine = torch.stack(local_stats).double()                 # (ROLLOUTS * T, STAT_WORDS): this rank's own statistics
+    all_stats = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(all_stats, mine)
+    tot = torch.stack(all_stats).sum(0)
+    cs = 0
+    for r, (res, st) in enumerate(results):
+        sl = slice(r * T, (r + 1) * T)
+        # whole-population statistics = mean of the ranks' (equal shards), counts summed
+        assert torch.allclose(st["timeout_rate"], tot[sl, S["TIMEOUT_RATE"]] / world)
+        assert torch.allclose(st["failure_rate"], tot[sl, S["FAILURE_RATE"]] / world)
+        assert torch.allclose(st["num_resets"], tot[sl, S["NUM_RESETS"]])
+        for t in range(T):
+            cs = min(cs + 1, buf.max_consecutive_successes) if tot[r * T + t, S["SUCCESS_RATE"]] > 0 else 0
+            assert float(st["consecutive_successes"][t]) == cs
+        if res is None:
+            assert mode == "learner" and rank != 0
+            continue
+        obs_g, rew_g, done_g = res
+        assert obs_g.shape == (T, world * N, env.num_observations)
+        for t in range(T):
+            o, rw, d = local[r * T + t]
+            assert torch.equal(obs_g[t, rank * N:(rank + 1) * N], o)
+            assert torch.equal(rew_g[t, rank * N:(rank + 1) * N], rw)
+            assert torch.equal(done_g[t, rank * N:(rank + 1) * N].bool(), d)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "timeout_rate.npy"), torch.cat([st["timeout_rate"] for _, st in results]).numpy())
+        np.save(os.path.join(out_dir, "rank0_timeout_rate.npy"), mine[:, S["TIMEOUT_RATE"]].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sink_path_with_in_flight_gather_and_reduced_statistics(tmp_path):
+    """the gloo tests drove add(), not the sink() + gather_async() path of bench.py; and the logging
+    rates / consecutive successes were per-rank.  Both modes."""
+    for mode in ("learner", "all"):
+        world, port = 2, _free_port()
+        mp.spawn(_sink_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+        glob, r0 = np.load(tmp_path / "timeout_rate.npy"), np.load(tmp_path / "rank0_timeout_rate.npy")
+        assert r0.max() == 1.0 and (glob[(r0 == 1.0)] >= 0.5).all() and (glob == 0.5).any()   # rank 0's all-env timeouts are half of the population's
+        assert (glob > 0).sum() > (r0 > 0).sum()              # steps in which only rank 1 timed out show up globally too
+
+
+def test_reduce_stats_consecutive_successes_single_process():
+    """The global consecutive-successes counter (termination_manager.py:323-339) from per-step success rates, carried
+    across rollouts and capped."""
+    from dexrobot_isaac_amd import _abi
+    from dexrobot_isaac_amd.rollout import RolloutBuffer
+    buf = RolloutBuffer(4, 3, 5, "cpu", max_consecutive_successes=5)
+    S = _abi.STAT
+    seqs = []
+    for flags in ([0, 1, 1, 1], [1, 1, 1, 1], [1, 0, 1, 0]):
+        for f in flags:
+            st = torch.zeros(_abi.STAT_USED)
+            st[S["SUCCESS_RATE"]] = f / 3.0
+            buf.add(torch.zeros(3, 5), torch.zeros(3), torch.zeros(3, dtype=torch.bool), stats=st)
+        seqs.append(buf.gather_async().stats()["consecutive_successes"].tolist())
+    assert seqs == [[0, 1, 2, 3], [4, 5, 5, 5], [5, 0, 1, 0]]
