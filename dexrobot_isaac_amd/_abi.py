@@ -85,6 +85,7 @@ class DexSimConfig(C.Structure):
         ("position_drift_tolerance", f32), ("velocity_tolerance", f32),
         ("dr_enabled", i32), ("dr_mass_lo", f32), ("dr_mass_hi", f32), ("dr_mu_lo", f32), ("dr_mu_hi", f32),
         ("dr_seed", u32),
+        ("box_fixed", i32), ("box_fixed_pos", f32 * 3),
     ]
 
 

@@ -298,12 +298,24 @@ def build_sim_config(cfg, model=None, dr=None):
         c.reward_weight[i] = w
 
     c.ground_friction = 0.5                                                    # dexhand_base.py:635-636
-    c.has_box = int(c.task == _abi.TASK_BLIND_GRASPING)
-    if c.has_box:
+    # env.box.fixed (new key): the harness's static contact-test box (examples/dexhand_test.py:950-1024, gym.create_box with
+    # fix_base_link = True, 0.1 m cube centred at (0.3, 0, 0.05)) as a config option -- for either task
+    fixed_box = bool((env.get("box") or {}).get("fixed", False))
+    c.has_box = int(c.task == _abi.TASK_BLIND_GRASPING or fixed_box)
+    if fixed_box:
         box = env["box"]
-        c.box_size, c.box_mass, c.box_friction = float(box["size"]), float(box["mass"]), float(box["friction"])
+        c.box_fixed = 1
+        c.box_size, c.box_mass, c.box_friction = float(box.get("size", 0.1)), 1.0, float(box.get("friction", 1.0))
+        pos = box.get("position", (0.3, 0.0, 0.5 * c.box_size))
+        for i in range(3):
+            c.box_fixed_pos[i] = float(pos[i])
+        c.box_z = float(pos[2])
+    if c.task == _abi.TASK_BLIND_GRASPING:
+        box = env["box"]
+        if not fixed_box:
+            c.box_size, c.box_mass, c.box_friction = float(box["size"]), float(box["mass"]), float(box["friction"])
+            c.box_z = float(box["initial_position"]["z"])
         c.box_xy_range = float(box["initial_position"]["xy_range"])
-        c.box_z = float(box["initial_position"]["z"])
         c.height_threshold = float(task["success_height_threshold"])
         c.contact_duration_threshold_s = float(task["contact_duration_threshold"])
         c.contact_duration_threshold_steps = int(float(task["contact_duration_threshold"]) / control_dt)

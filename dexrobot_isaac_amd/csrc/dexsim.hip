@@ -167,7 +167,8 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
   if (cfg->num_obs <= 0 || cfg->n_obs_seg <= 0 || cfg->n_obs_seg > DEXSIM_MAX_OBS_SEG) return fail(DEXSIM_ERR_ARG, "dexsim_create: bad observation table");
   if (cfg->num_actions != 6 * (cfg->policy_controls_base != 0) + 12 * (cfg->policy_controls_fingers != 0) || cfg->num_actions == 0)
     return fail(DEXSIM_ERR_ARG, "dexsim_create: num_actions inconsistent with policy_controls_*");
-  if (cfg->has_box && !(cfg->box_size > 0.f && cfg->box_mass > 0.f)) return fail(DEXSIM_ERR_ARG, "dexsim_create: bad box");
+  if (cfg->has_box && !(cfg->box_size > 0.f && (cfg->box_mass > 0.f || cfg->box_fixed))) return fail(DEXSIM_ERR_ARG, "dexsim_create: bad box");
+  if (cfg->box_fixed && !cfg->has_box) return fail(DEXSIM_ERR_ARG, "dexsim_create: box_fixed needs has_box");
   {
     int tot = 0;
     for (int s = 0; s < cfg->n_obs_seg; s++) {

@@ -236,6 +236,12 @@ typedef struct DexSimConfig {
   int   dr_enabled;
   float dr_mass_lo, dr_mass_hi, dr_mu_lo, dr_mu_hi;
   uint32_t dr_seed;
+  /* static box actor (the harness's contact-test box, examples/dexhand_test.py:950-1024: gym.create_box with
+   * fix_base_link = True at a fixed pose, identity orientation).  With box_fixed the box never moves: no gravity, no
+   * box/ground contacts, infinite mass in the hand/box contact rows; resets leave it where it is.  Works with either task
+   * (BaseTask has no box of its own: has_box = 1 then adds the second actor). */
+  int   box_fixed;
+  float box_fixed_pos[3];
 } DexSimConfig;
 
 /* ------------------------------------------------------------------ arena layout */

@@ -441,7 +441,7 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
     real mu_bg = (real)0.5 * (e->box_mu + cfg->ground_friction);
     /* at most 4 box/ground contacts (a cube touches a plane with at most 4 corners; more only when it is buried), in
      * corner-index order */
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 8 && !cfg->box_fixed; i++) {   /* (a static box is not a dynamic body: no box/ground rows) */
       real l[3] = {(i & 1) ? hb[0] : -hb[0], (i & 2) ? hb[1] : -hb[1], (i & 4) ? hb[2] : -hb[2]}, p[3];
       m3v(p, Rb, l); v3add(p, p, e->box_pos);
       if (p[2] < co && e->ncontact < 4) push_contact(e, 2, -1, i, p, zup, p[2] - rest, mu_bg);
@@ -523,11 +523,11 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     for (int i = 0; i < NJ; i++) v[i] = e->qd[i] + h * a[i];
   }
   real inv_m = 0, inv_I = 0;
-  if (cfg->has_box) {
+  if (cfg->has_box && !cfg->box_fixed) {
     inv_m = 1 / e->box_mass;
     inv_I = 1 / (e->box_mass * cfg->box_size * cfg->box_size / 6); /* solid cube */
     for (int i = 0; i < 3; i++) { v[26 + i] = e->box_lin[i] + h * g[i]; v[29 + i] = e->box_ang[i]; }
-  } else for (int i = 26; i < NV; i++) v[i] = 0;
+  } else for (int i = 26; i < NV; i++) v[i] = 0;   /* no box, or the static box of the harness (fix_base_link): 1/m = 1/I = 0 */
 
   collide(o, e, &fk);
   int K = e->ncontact;
@@ -696,7 +696,7 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     if (qn > m->hi[i]) { qn = m->hi[i]; vn = minr(vn, 0); }
     e->q[i] = qn; e->qd[i] = vn;
   }
-  if (cfg->has_box) {
+  if (cfg->has_box && !cfg->box_fixed) {
     for (int i = 0; i < 3; i++) { e->box_lin[i] = v[26 + i]; e->box_ang[i] = v[29 + i]; e->box_pos[i] += h * v[26 + i]; }
     real wq[4] = {e->box_ang[0], e->box_ang[1], e->box_ang[2], 0}, dq[4];
     qmul(dq, wq, e->box_quat);
@@ -1096,9 +1096,11 @@ static void reset_env(const Oracle* o, OrcEnv* e, int idx) {
     }
     real x = (u[0] * 2 - 1) * c->box_xy_range, y = (u[1] * 2 - 1) * c->box_xy_range;
     real yaw = (u[2] * 2 - 1) * (real)3.14159265358979323846;
-    v3set(e->box_pos, x, y, c->box_z);
-    v3set(e->initial_box_pos, x, y, c->box_z);
-    e->box_quat[0] = 0; e->box_quat[1] = 0; e->box_quat[2] = RSIN(yaw / 2); e->box_quat[3] = RCOS(yaw / 2);
+    if (!c->box_fixed) {   /* (a static box stays where it was created) */
+      v3set(e->box_pos, x, y, c->box_z);
+      v3set(e->initial_box_pos, x, y, c->box_z);
+      e->box_quat[0] = 0; e->box_quat[1] = 0; e->box_quat[2] = RSIN(yaw / 2); e->box_quat[3] = RCOS(yaw / 2);
+    }
     for (int i = 0; i < 3; i++) { e->box_lin[i] = 0; e->box_ang[i] = 0; }
     e->success_duration_steps = 0; e->success_conditions_met = 0;
     e->current_stage = 1; e->time_in_stage = 0; e->stage_contact_duration = 0; e->just2 = 0; e->just3 = 0;
@@ -1157,6 +1159,7 @@ void orc_init_state(void* h) {
     OrcEnv* e = &o->env[i];
     memset(e, 0, sizeof *e);
     e->box_quat[3] = 1; e->box_pos[2] = c->box_z; e->initial_box_pos[2] = c->box_z;
+    if (c->box_fixed) for (int k = 0; k < 3; k++) { e->box_pos[k] = c->box_fixed_pos[k]; e->initial_box_pos[k] = c->box_fixed_pos[k]; }
     e->box_mass = c->box_mass > 0 ? c->box_mass : 1; e->box_mu = c->box_friction;
     if (c->dr_enabled) {
       uint32_t x[4];

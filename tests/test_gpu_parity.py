@@ -854,10 +854,11 @@ def test_generic_sweep_variants_match_oracle(z):
     assert np.isfinite(hb.get("q")).all() and np.abs(hb.get("q") - o.get("q")).max() < 5e-3
 
 
-@pytest.mark.parametrize("substeps,iters", [(2, 8), (8, 32)], ids=["physics=fast", "8 sub-steps / 32 iterations"])
+@pytest.mark.parametrize("substeps,iters", [(2, 8), (8, 32), (32, 32)], ids=["physics=fast", "8 sub-steps / 32 iterations", "physics=accurate"])
 def test_other_substep_counts_use_the_staged_path(substeps, iters):
-    """cfg/physics/fast.yaml (substeps 2, 8 position iterations) and a heavier setting in the direction of
-    cfg/physics/accurate.yaml (the reference's 32 x 32, shortened here): sub-step counts other than 4 run dexsim_step as
+    """cfg/physics/fast.yaml (substeps 2, 8 position iterations), a heavier setting in the direction of
+    cfg/physics/accurate.yaml, and accurate.yaml itself at its real 32 sub-steps x 32 iterations (round 3; timed by
+    `bench.py --substeps 32 --iterations 32`): sub-step counts other than 4 run dexsim_step as
     the staged launches (k_actions, `substeps` x k_substep, k_post, k_reset, gated physics, k_reset).  Whole control steps
     with in-step resets against the oracle; the integer bookkeeping must agree exactly."""
     from oracle.oracle import Oracle
@@ -979,3 +980,160 @@ def test_warm_start_generation_wrap_on_the_hip_path():
                     + [quad[:, :n, :3].clone()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_config3_headline_workload_as_itself_through_the_synchronous_reset():
+    """BASELINE configs[2] as itself: BlindGrasping, num_envs = 4096, random actions, default
+    config, 205 control steps from a fresh reset -- through the one event that defines the headline workload: at t = 4 s
+    (control step 200) every env fails the stage-1 pre-grasp check and all 4096 reset IN THE SAME STEP (the device-gated
+    second physics step runs exactly once).  HIP vs the oracle on the same actions and the same Philox reset stream.
+    Tolerances: free-running bar (no hand contacts in this regime: the error does not grow through contacts) -- median obs
+    error < 1e-4, 99.9th percentile < 5e-3 over ALL 205 steps; rewards 2e-2 abs; done flags, reset counts and physics-step
+    counts exact."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 4096
+    sc, model = _mk("BlindGrasping", n)
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms, threads=16), HipBackend(sc, ms)
+    np.testing.assert_allclose(hb.reset(), o.reset(), atol=2e-4)
+    rng = np.random.default_rng(2024)
+    errs, sync_steps = [], []
+    for t in range(205):
+        a = (2 * rng.random((n, 18)) - 1).astype(np.float32)
+        oo, ro, do = o.step(a)
+        oh, rh, dh = hb.step(a)
+        errs.append(np.abs(oh - oo).max(axis=1))
+        assert (do == dh.astype(bool)).all(), t
+        np.testing.assert_allclose(rh, ro, atol=2e-2, rtol=1e-4)
+        assert hb.stats()[16] == o.stats()[16] and hb.stats()[17] == (2 if do.any() else 1)
+        if do.any():
+            sync_steps.append((t, int(do.sum())))
+    assert sync_steps == [(199, n)], sync_steps               # the synchronous all-env reset, once, at control step 200
+    errs = np.stack(errs)
+    assert np.median(errs) < 1e-4 and np.percentile(errs, 99.9) < 5e-3, (np.median(errs), np.percentile(errs, 99.9), errs.max())
+    assert np.median(errs[200:]) < 1e-4                        # the new episodes start from the same Philox samples
+    assert (hb.get("reset_count") == o.get("reset_count")).all() and int(o.get("reset_count").min()) == 2
+    fr_h, fr_o = hb.get("failure_reason"), o.get("failure_reason")
+    assert (fr_h == fr_o).all()
+    assert float(hb.stats()[19]) == 0.0 and float(hb.stats()[18]) == 4.0     # the regime: no hand contact, the box on its 4 corners
+
+
+@pytest.mark.gpu
+def test_loaded_mjcf_with_perturbed_numbers_drives_the_hip_path():
+    """f-3 on the GPU: a hand model with PERTURBED link lengths, masses, capsule radii, gains and joint
+    ranges goes through export_mjcf -> load_mjcf -> make_env(hand_model=...) on the HIP path and is compared with the
+    oracle driven by the same loaded model: the model's numbers are run-time data of the kernels, not constants compiled
+    into them.  (No real DexHand MJCF exists offline -- absent submodule -- so the file is this build's own export.)
+    Free-running control steps + a teacher-forced contact sub-step; the default model must give DIFFERENT outputs."""
+    import torch
+    from dexrobot_isaac_amd import default_cfg, make_env
+    from dexrobot_isaac_amd.hand_model import HandModel
+    from dexrobot_isaac_amd.mjcf import export_mjcf, load_mjcf
+    from oracle.oracle import Oracle
+    from oracle.py_backend import OracleCore
+    from tests.hip_backend import HipBackend
+
+    class Perturbed(HandModel):
+        L_PROX = [0.043, 0.037, 0.049, 0.042, 0.030]
+        L_MID = [0.027, 0.028, 0.025, 0.027, 0.023]
+        L_DIST = [0.022, 0.024, 0.027, 0.020, 0.018]
+        R_PROX = [0.0095, 0.0075, 0.0085, 0.0078, 0.0070]
+        R_MID = [0.0080, 0.0080, 0.0070, 0.0072, 0.0066]
+        R_DIST = [0.0075, 0.0066, 0.0074, 0.0068, 0.0061]
+        M_PALM = 0.41
+        M_LINK = [0.005, 0.012, 0.010, 0.006]
+        PALM_CAP_R = 0.0135
+
+    pm = Perturbed()
+    pm.kp[6:] = 24.0
+    pm.kd[6:] = 0.8
+    pm.hi[7::4] = 0.9
+    pm.armature[6:] = 2e-5
+    loaded = load_mjcf(export_mjcf(pm))
+    n = 128
+    cfg = default_cfg("BlindGrasping")
+    cfg["env"]["episodeLength"] = 14
+    env = make_env("BlindGrasping", n, "cuda:0", "cuda:0", 0, cfg=cfg, hand_model=loaded)
+    ref = make_env("BlindGrasping", n, "cpu", "cpu", 0, cfg=cfg, hand_model=loaded, _core_factory=OracleCore)
+    dflt = make_env("BlindGrasping", n, "cuda:0", "cuda:0", 0, cfg=cfg)
+    np.testing.assert_allclose(env.reset().cpu().numpy(), ref.reset().numpy(), atol=2e-4)
+    dflt.reset()
+    g = torch.Generator().manual_seed(11)
+    worst = 0.0
+    for t in range(18):
+        a = 2 * torch.rand(n, 18, generator=g) - 1
+        og, rg, dg, _ = env.step(a.cuda())
+        orr, rr, dr, _ = ref.step(a)
+        od, _, _, _ = dflt.step(a.cuda())
+        worst = max(worst, float((og.cpu() - orr).abs().max()))
+        assert (dg.cpu() == dr).all()
+        np.testing.assert_allclose(rg.cpu().numpy(), rr.numpy(), atol=2e-2, rtol=1e-4)
+    assert worst < 2e-3, worst
+    assert float((og - od).abs().max()) > 1e-2               # the perturbed numbers really reached the kernels
+    assert torch.allclose(env.dof_props.cpu(), torch.tensor(loaded.dof_props()))
+    env.close(), dflt.close()
+    # teacher-forced sub-step in a contact state (hands low over their boxes): contact lists and velocities vs the oracle
+    sc, _ = build_sim_config({**cfg, "env": {**cfg["env"], "numEnvs": n}}, model=loaded)
+    ms = loaded.to_struct()
+    o, hb = Oracle(sc, ms), HipBackend(sc, ms)
+    rng = np.random.default_rng(5)
+    q = np.zeros((26, n))
+    q[2] = rng.uniform(-0.43, -0.38, n)
+    q[6:] = rng.uniform(0.0, 0.3, (20, n))
+    for b in (o, hb):
+        b.set("q", q); b.set("qd", 0 * q); b.set("targets", q)
+    for _ in range(3):
+        o.substep(True); hb.substep(True)
+    nc_o, nc_h = o.get("ncontact")[0], hb.get("ncontact")[0]
+    same = nc_o == nc_h
+    assert same.mean() > 0.97 and nc_o.mean() > 5.0
+    np.testing.assert_allclose(hb.get("q")[:, same], o.get("q")[:, same], atol=2e-4)
+    np.testing.assert_allclose(hb.get("qd")[:, same], o.get("qd")[:, same], atol=5e-3, rtol=2e-3)
+
+
+@pytest.mark.gpu
+def test_static_contact_test_box_of_the_reference_harness():
+    """The reference's contact smoke procedure (examples/dexhand_test.py:950-1024: BaseTask + a STATIC 0.1 m box --
+    gym.create_box, fix_base_link = True -- centred at (0.3, 0, 0.05) "beneath the middle finger"), f-4's last gap.  The
+    box is `env.box = {fixed: true, size, position}`; the hand is driven over it and lowered through make_env().step() in
+    `position` mode until the middle fingertip presses on the box top.  Asserts, on the HIP path and against the oracle: a
+    contact force appears on the middle finger's distal link r_f_link3_4 (contact_forces[:, 2]) and nowhere else on the
+    hand, contact_binary of the obs_dict follows it, the box does not move by a single bit, the root-state tensor has the
+    second actor."""
+    import torch
+    from dexrobot_isaac_amd import default_cfg, make_env
+    from oracle.py_backend import OracleCore
+    cfg = default_cfg("BaseTask")
+    cfg["task"]["controlMode"] = "position"
+    cfg["env"]["episodeLength"] = 100000
+    cfg["env"]["box"] = {"fixed": True, "size": 0.1, "position": [0.3, 0.0, 0.05], "friction": 1.0}
+    n = 70
+    env = make_env("BaseTask", n, "cuda:0", "cuda:0", 0, cfg=cfg)
+    ref = make_env("BaseTask", n, "cpu", "cpu", 0, cfg=cfg, _core_factory=OracleCore)
+    env.reset(), ref.reset()
+    assert env.actor_root_state_tensor.shape == (n, 2, 13) and env.num_observations == 224
+    box0 = env.actor_root_state_tensor[:, 1].clone()
+    assert torch.allclose(box0[0, :7], torch.tensor([0.3, 0.0, 0.05, 0, 0, 0, 1.0], device="cuda:0"))
+    lo, hi = env.action_processor.active_lower_limits, env.action_processor.active_upper_limits
+    a = torch.zeros(n, 18)
+    a[:, 6:] = -1.0                                             # fingers open (position mode: -1 = lower limit)
+    x_t = torch.linspace(0.28, 0.32, n)                         # a little spread over the box top, all under the middle finger
+    a[:, 0] = 2 * (x_t - float(lo[0])) / float(hi[0] - lo[0]) - 1
+    z_t = -0.1925
+    a[:, 2] = 2 * (z_t - float(lo[2])) / float(hi[2] - lo[2]) - 1
+    for t in range(260):                                        # max_base_linear_velocity caps the approach
+        og, _, _, _ = env.step(a.cuda())
+        orr, _, _, _ = ref.step(a)
+    cf_g, cf_r = env.contact_forces.cpu(), ref.contact_forces
+    mag = cf_g.norm(dim=2)
+    assert (mag[:, 2] > 5.0).all() and float(mag[:, [0, 1, 3, 4]].max()) == 0.0     # the middle finger, only
+    np.testing.assert_allclose(cf_g.numpy(), cf_r.numpy(), rtol=2e-2, atol=0.2)
+    od = env.get_observations_dict()
+    assert (od["contact_binary"][:, 2] == 1).all() and float(od["contact_binary"][:, [0, 1, 3, 4]].sum()) == 0
+    assert torch.equal(env.actor_root_state_tensor[:, 1], box0)                     # static: not a bit of motion
+    np.testing.assert_allclose(og.cpu().numpy(), orr.numpy(), atol=2e-3)
+    tip_z = od["fingertip_poses_world"][:, 7 * 2 + 2]
+    assert float((tip_z - (0.1 + 0.007)).abs().max()) < 4e-3   # tip sphere (r = 7 mm) rests on the box top z = 0.1
+    env.close()
