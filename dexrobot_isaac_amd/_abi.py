@@ -7,7 +7,7 @@ import ctypes as C
 
 NJ, NBASE, NFINGER, NFJ, NACT = 26, 6, 5, 4, 18
 NSITE, NCAP, NFSLOT, KMAX = 11, 18, 17, 24
-NWKEY = 88      # DEXSIM_NWKEY: warm-start cache slots per env
+NWKEY = 128     # DEXSIM_NWKEY: warm-start cache slots per env
 FSLOT_PALM, FSLOT_BOX = 15, 16
 NRESET_SAMPLES = 29
 MAX_OBS_SEG = 40
@@ -86,6 +86,7 @@ class DexSimConfig(C.Structure):
         ("dr_enabled", i32), ("dr_mass_lo", f32), ("dr_mass_hi", f32), ("dr_mu_lo", f32), ("dr_mu_hi", f32),
         ("dr_seed", u32),
         ("box_fixed", i32), ("box_fixed_pos", f32 * 3),
+        ("joint_limit_rows", i32), ("joint_limit_margin", f32),
     ]
 
 
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "dexsim_body_name", "dexsim_create", "dexsim_destroy", "dexsim_bind", "dexsim_init_state",
     "dexsim_process_actions", "dexsim_begin_step", "dexsim_physics_step", "dexsim_post_physics", "dexsim_step",
     "dexsim_reset_idx", "dexsim_reset", "dexsim_refresh_body_states", "dexsim_set_dof_state_indexed",
-    "dexsim_set_root_state_indexed", "dexsim_run_stage", "dexsim_time_stage", "dexsim_step_timing", "dexsim_set_step_sink", "dexsim_set_stats_sink", "dexsim_set_action_copy", "dexsim_error_string",
+    "dexsim_set_root_state_indexed", "dexsim_run_stage", "dexsim_time_stage", "dexsim_step_timing", "dexsim_set_step_sink", "dexsim_set_stats_sink", "dexsim_set_phase_probe", "dexsim_set_obs_dict_mode", "dexsim_set_action_copy", "dexsim_error_string",
     "dexsim_last_error",
 ]
 
@@ -145,6 +146,8 @@ def declare_prototypes(lib):
     lib.dexsim_set_step_sink.argtypes = [vp, vp, vp, vp]
     lib.dexsim_set_action_copy.argtypes = [vp, vp]
     lib.dexsim_set_stats_sink.argtypes = [vp, vp]
+    lib.dexsim_set_phase_probe.argtypes = [vp, vp]
+    lib.dexsim_set_obs_dict_mode.argtypes = [vp, i32]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name).restype = i32
     lib.dexsim_error_string.argtypes = [i32]

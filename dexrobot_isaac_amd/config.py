@@ -224,6 +224,10 @@ def build_sim_config(cfg, model=None, dr=None):
     c.rest_offset = float(px["rest_offset"])
     c.max_depenetration_velocity = float(px["max_depenetration_velocity"])
     c.erp = float(sim.get("dexsim_erp", 0.2))
+    # sim.dexsim_joint_limit_rows (new key, default off): joint limits as unilateral rows of the contact solver for finger joints
+    # within sim.dexsim_joint_limit_margin (rad) of a limit, in envs with hand contacts (include/dexsim.h: joint_limit_rows)
+    c.joint_limit_rows = int(bool(sim.get("dexsim_joint_limit_rows", False)))
+    c.joint_limit_margin = float(sim.get("dexsim_joint_limit_margin", 0.01))
     control_dt = 2.0 * float(sim["dt"])   # python double, as PhysicsManager computes it (physics_manager.py:259)
     c.control_dt = control_dt
     c.episode_length = int(env["episodeLength"])

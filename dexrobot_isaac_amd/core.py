@@ -189,6 +189,17 @@ class DexSimCore:
         check(self.lib.dexsim_set_step_sink(self.h, ptr(obs, torch.float32, (self.N, int(self.cfg.num_obs))),
                                             ptr(rew, torch.float32, (self.N,)), ptr(done, torch.uint8, (self.N,))), "set_step_sink")
 
+    def set_obs_dict_mode(self, policy_only):
+        """False: every obs_dict row is materialised each step (default); True: only obs_buf (the policy keys) is written."""
+        check(self.lib.dexsim_set_obs_dict_mode(self.h, 1 if policy_only else 0), "set_obs_dict_mode")
+
+    def set_phase_probe(self, on=True):
+        """Switch the phase probe on (returns the zeroed (num_workgroups, 4) int32 tensor the kernels accumulate shader-clock
+        ticks into: [:, 0] contact rows + sweeps, [:, 1] whole physics launch, [:, 2] general-path sub-steps, [:, 3] sweeps) or off."""
+        self._probe = torch.zeros(self.NS // 64, 4, dtype=torch.int32, device=self.device) if on else None
+        check(self.lib.dexsim_set_phase_probe(self.h, None if self._probe is None else C.c_void_p(self._probe.data_ptr())), "set_phase_probe")
+        return self._probe
+
     def set_stats_sink(self, dst):
         """(STAT_WORDS,) f32 row that receives a copy of every step's statistics block (dexsim_set_stats_sink), or None."""
         if dst is not None:

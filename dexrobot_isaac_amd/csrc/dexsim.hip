@@ -565,6 +565,19 @@ int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done) {
   return DEXSIM_OK;
 }
 
+int dexsim_set_obs_dict_mode(dexsim_t h, int mode) {
+  if (!h) return fail(DEXSIM_ERR_ARG, "null handle");
+  if (mode != 0 && mode != 1) return fail(DEXSIM_ERR_ARG, "dexsim_set_obs_dict_mode: mode must be 0 (all rows) or 1 (policy keys only)");
+  h->api.skip_obs_all = mode;   // kernel argument: effective from the next launch
+  return DEXSIM_OK;
+}
+
+int dexsim_set_phase_probe(dexsim_t h, uint32_t* buf) {
+  if (!h) return fail(DEXSIM_ERR_ARG, "null handle");
+  h->api.probe = buf;   // kernel argument: effective from the next launch
+  return DEXSIM_OK;
+}
+
 int dexsim_set_stats_sink(dexsim_t h, float* dst) {
   if (!h) return fail(DEXSIM_ERR_ARG, "null handle");
   h->api.sink_stats = dst;   // kernel argument: effective from the next launch

@@ -18,7 +18,7 @@
   /* compact L1 state read by the fused post-physics kernel */                                              \
   X(float, site_pose, 77) X(float, hand_vel, 6) X(float, cforce, 51) X(float, cf5, 15)                      \
   /* dynamics -> contact-solve interface (one sub-step) */                                                  \
-  X(float, jframe, 156) X(float, ufree, 32) X(float, fac_sinv, 21) X(float, fac_finv, 50)                   \
+  X(float, jframe, 156) X(float, ufree, 32) X(float, fac_sinv, 21) X(float, fac_finv, 60)                   \
   X(float, fac_g, 120) X(int, ncontact, 1) X(float, cgeom, DEXSIM_KMAX * 8) X(int, ccode, DEXSIM_KMAX)      \
   X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28 + 4) X(float, cbias, DEXSIM_KMAX) X(float, clam, DEXSIM_KMAX * 3) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * 15 * 9)                                         \
   /* warm-start cache: per contact key one float4 (impulses of the previous sub-step, tag), [key][env][4]; wgen = the env's sub-step generation */ \
@@ -44,6 +44,17 @@ struct Arena {
   DEXSIM_FIELDS(X)
 #undef X
 };
+
+// Quad layout (round 3): the per-finger factor hand-off -- fac_g (G_f, 24 words = 6 quads per finger), fac_finv (Fhat_f^-1 lower
+// triangle, 10 words in 3 quads per finger) and the finger part of jframe (axes + origins of the finger's 4 joints, 24 words = 6
+// quads per finger, behind the 36 row-layout words of the base joints) -- is stored [quad][env][4]: a lane moves four consecutive
+// words with ONE 16-byte access.  G_f alone is written and read back by every finger wave in every sub-step: 48 memory instructions
+// become 12; the row builder's 58 dependent scalar loads become 15.
+#define FQ(field, quad) ((__attribute__((address_space(1))) f4*)(A.field) + ((size_t)(quad) * N + e))
+#define JFRAME_FQ0 9   /* first quad of finger 0's joint frames in jframe (36 base-joint words come first) */
+// the manifold (cgeom: 2 quads per list entry: p.xyz n.x | n.yz gap mu) and the narrowphase staging blocks (cstage: 2 quads per staged
+// contact, 6 waves x 15; their codes as plain rows behind the 180 quads) are FQ fields too
+#define CSTAGE_CODE0 720
 
 #define CROW_W 28 /* words per contact row: t6 jf4 St6 Fj4 d3 rxd3 Dinv pad */
 // crowq: the rows of streamed hand contacts in the quad layout of the LDS row store ([quad][env] of float4, 21 quads per

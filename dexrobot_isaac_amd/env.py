@@ -232,6 +232,24 @@ class _ObservationEncoderView:
         return data[env_idx].item() if env_idx is not None else data
 
 
+class _PolicyObsDict(dict):
+    """obs_dict in mode "policy" (env.obsDict: policy): the policy keys are views of obs_buf; every other key of the reference's
+    obs_dict exists in the reference but is not materialised here -- asking for one is an error that says how to get it."""
+
+    def __init__(self, views, all_keys):
+        super().__init__(views)
+        self._all_keys = set(all_keys)
+
+    def copy(self):
+        return _PolicyObsDict(dict(self), self._all_keys)
+
+    def __missing__(self, key):
+        if key in self._all_keys:
+            raise KeyError(f"obs_dict['{key}'] is not materialised in env.obsDict = 'policy' mode (only the policy_observation_keys "
+                           f"are: {sorted(self)}); create the env with cfg['env']['obsDict'] = 'all' (the default) to read it")
+        raise KeyError(key)
+
+
 class _TerminationManagerView:
     def __init__(self, env):
         self._env = env
@@ -363,8 +381,22 @@ class DexHandEnv:
         offs = obs_key_offsets()
         oa = core.field("obs_all")
         n_keys = len(OBS_KEYS) if c.task == _abi.TASK_BLIND_GRASPING else 23
-        self.obs_dict = {}
+        # env.obsDict (new key): "all" (default) = every key of the reference's obs_dict is materialised each step (392 SoA rows per
+        # env); "policy" = only obs_buf is written and obs_dict serves the policy keys as views of it -- what a training loop
+        # needs (dexsim_set_obs_dict_mode; 1 568 B per env and step less to write)
+        self.obs_dict_mode = str(self.env_cfg.get("obsDict", "all"))
+        if self.obs_dict_mode not in ("all", "policy"):
+            raise ValueError(f"env.obsDict must be 'all' or 'policy', got '{self.obs_dict_mode}'")
+        if self.obs_dict_mode == "policy" and hasattr(core, "set_obs_dict_mode"):
+            core.set_obs_dict_mode(True)
+            views = {k: self.obs_buf[:, a:b] for k, (a, b) in self.observation_encoder.component_slice_indices.items()}
+            self.obs_dict = _PolicyObsDict(views, [k for k, _ in OBS_KEYS[:n_keys]])
+        else:
+            self.obs_dict_mode = "all"
+            self.obs_dict = {}
         for name, dim in OBS_KEYS[:n_keys]:
+            if self.obs_dict_mode != "all":
+                break
             off, _ = offs[name]
             if name == "prev_actions":
                 dim = int(c.num_actions)
@@ -459,6 +491,8 @@ class DexHandEnv:
         rule = self.action_processor._pre_action_rule
         if rule is None:       # identity default already written by the post kernel
             return
+        if self.obs_dict_mode != "all":
+            raise RuntimeError("a custom pre-action rule reads the full obs_dict: create the env with env.obsDict = 'all' (the default)")
         out = rule(self.obs_dict["active_prev_targets"].clone(), {"obs_dict": self.obs_dict, "env": self})
         self._core.field("active_rule_targets").copy_(out.t())
         off, dim = obs_key_offsets()["active_rule_targets"]

@@ -39,8 +39,9 @@ extern "C" {
 #define DEXSIM_KMAX      24   /* max active contacts per env per sub-step (<= 4 box/ground + hand contacts in priority order) */
 #define DEXSIM_BISECT_ITERS 10 /* capsule / box narrowphase: bisection steps for the point of the capsule axis nearest to the box
                                 (2^-10 of the axis, ~30 um; the gap is stationary there: its error is second order) */
-#define DEXSIM_NWKEY 88      /* warm-start cache slots of the contact solver: (capsule * 2 + type) * 2 + sample for hand contacts (< 72),
-                                80 + list slot for the (<= 4) box/ground contacts (their tag carries the box corner) */
+#define DEXSIM_NWKEY 128     /* warm-start cache slots of the contact solver: (capsule * 2 + type) * 2 + sample for hand contacts (< 72),
+                                80 + list slot for the (<= 4) box/ground contacts (their tag carries the box corner),
+                                88 + (finger joint * 2 + side) for the joint-limit rows (side 0 = lower, 1 = upper) */
 /* the warm-start generation of an env advances once per sub-step and once per reset; it wraps at 2^27 so that the cache tags
    8 * generation + corner stay below 2^30 in signed 32-bit arithmetic for any run length (a generation is only ever compared
    with the one before it: a tag can falsely match only if its slot sat unwritten for exactly 2^27 generations) */
@@ -242,6 +243,14 @@ typedef struct DexSimConfig {
    * (BaseTask has no box of its own: has_box = 1 then adds the second actor). */
   int   box_fixed;
   float box_fixed_pos[3];
+  /* Joint limits as unilateral solver rows (round 3; the reference's limits are PhysX articulation limits, dof_props lower / upper,
+   * tensor_manager.py:547-554).  With joint_limit_rows != 0 every finger joint within joint_limit_margin (rad) of a limit gets a
+   * one-row speculative constraint (J = +-e_j, gap = distance to the limit, no friction) in the contact solver -- in envs that have
+   * at least one hand contact in the sub-step: without contact forces the PD drive cannot push a joint across a limit its own
+   * target respects, and the position clamp behind the integration stays as the safety net in every case.  List order: a
+   * finger's limit rows follow that finger's contacts; they count against DEXSIM_KMAX. */
+  int   joint_limit_rows;
+  float joint_limit_margin;
 } DexSimConfig;
 
 /* ------------------------------------------------------------------ arena layout */
@@ -367,6 +376,20 @@ int dexsim_set_step_sink(dexsim_t h, float* obs, float* rew, uint8_t* done);
  * envs sharded over ranks can reduce their whole-population statistics with ONE small all-reduce per rollout (rollout.py:
  * reduce_stats) instead of one per step.  NULL switches it off.  Kernel argument like the step sink. */
 int dexsim_set_stats_sink(dexsim_t h, float* dst);
+
+/* get_observations_dict() (dexhand_base.py:948-956) is served from the arena field obs_all: 392 SoA rows per env that the post
+ * block writes in every step (mode 0, the default: every key of the reference's obs_dict is a view).  A training loop reads
+ * obs_buf only -- the configured policy keys -- so mode 1 ("policy") stops materialising the rows: 1 568 B per env and step less
+ * to write; the host side then serves the policy keys as views of obs_buf and raises on any other key.  Kernel argument. */
+int dexsim_set_obs_dict_mode(dexsim_t h, int mode);
+
+/* Phase probe (measurement, SURVEY.md 8d: the contact-solve sub-metric on the PRODUCTION kernel): with `buf` set --
+ * 4 x ceil(num_envs / 64) uint32 on the device, zeroed by the caller -- every following physics launch of the 4-sub-step path
+ * adds, per workgroup, shader-clock ticks (s_memtime) to buf[4 w + 0] = phases 3 + 4 of the general contact path (contact rows +
+ * the block solver's sweeps), [4 w + 1] = the whole launch (ungated launches), [4 w + 3] = phase 4 alone, and counts in
+ * [4 w + 2] the sub-steps that ran the general path.  Solver time = launch time (HIP events) x buf[0] / buf[1].  NULL switches it
+ * off (the default; the probe then costs two scalar branches per sub-step). */
+int dexsim_set_phase_probe(dexsim_t h, uint32_t* buf);
 
 /* DexHandBase.pre_physics_step keeps `self.actions = actions.clone()` (dexhand_base.py:851).  With a destination set here
  * ((N, num_actions) f32 on the device, or NULL to switch off) the action block writes that copy itself, so the host side

@@ -137,9 +137,11 @@ static inline real u01(uint32_t x) { return (real)(x >> 8) * (real)(1.0 / 167772
 /* ------------------------------------------------------------------------------------------ state */
 typedef struct OrcContact {
   real p[3], n[3], gap, mu;
-  int type; /* 0 hand-ground, 1 hand-box, 2 box-ground */
-  int cap;  /* capsule index for hand contacts */
-  int key;  /* warm-start cache: hand contacts slot (cap * 2 + type) * 2 + sample; box/ground: the corner index (slot 80 + list index) */
+  int type; /* 0 hand-ground, 1 hand-box, 2 box-ground, 3 joint-limit row (cfg.joint_limit_rows) */
+  int cap;  /* capsule index for hand contacts; type 3: the joint's level in its finger (0..3) */
+  int key;  /* warm-start cache: hand contacts slot (cap * 2 + type) * 2 + sample; box/ground: the corner index (slot 80 + list index);
+             * type 3: slot 88 + (finger joint * 2 + side) */
+  int finger, side;   /* type 3: finger 0..4, side 0 = lower limit (J = +e_j), 1 = upper limit (J = -e_j) */
 } OrcContact;
 
 typedef struct OrcEnv {
@@ -399,6 +401,24 @@ static inline void push_contact(OrcEnv* e, int type, int cap, int sample, const 
   OrcContact* c = &e->contact[e->ncontact++];
   v3cpy(c->p, p); v3cpy(c->n, n); c->gap = gap; c->mu = mu; c->type = type; c->cap = cap;
   c->key = type == 2 ? sample : (cap * 2 + type) * 2 + sample;
+  c->finger = -1; c->side = 0;
+}
+
+/* Joint-limit rows of finger f (cfg.joint_limit_rows): every joint of the finger within the margin of a limit gets a one-row
+ * speculative constraint, lower before upper, proximal to distal; they follow the finger's contacts in the list */
+static inline void push_limit_rows(const Oracle* o, OrcEnv* e, int f) {
+  const DexHandModel* m = &o->model;
+  static const real zero3[3] = {0, 0, 0};
+  for (int l = 0; l < 4; l++) {
+    int j = 6 + 4 * f + l;
+    real gap[2] = {e->q[j] - m->lo[j], m->hi[j] - e->q[j]};
+    for (int sd = 0; sd < 2; sd++) {
+      if (!(gap[sd] < o->cfg.joint_limit_margin) || e->ncontact >= KMAX) continue;
+      push_contact(e, 3, l, sd, zero3, zero3, gap[sd], 0);
+      OrcContact* c = &e->contact[e->ncontact - 1];
+      c->finger = f; c->side = sd; c->key = 88 + (4 * f + l) * 2 + sd;
+    }
+  }
 }
 
 /* sphere (centre P in box frame, radius r) against the solid box of half extents h */
@@ -428,9 +448,17 @@ static inline real seg_box_dfdt(const real* a, const real* d, real t, const real
   return g;
 }
 
+static void collide_pass(const Oracle* o, OrcEnv* e, const FK* fk, int limit_rows, int* nreal);
 static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
+  /* joint-limit rows exist only in envs with at least one hand contact (counted before the list is cut at KMAX) */
+  int nreal = 0;
+  collide_pass(o, e, fk, o->cfg.joint_limit_rows, &nreal);
+  if (o->cfg.joint_limit_rows && nreal == 0) collide_pass(o, e, fk, 0, &nreal);
+}
+static void collide_pass(const Oracle* o, OrcEnv* e, const FK* fk, int limit_rows, int* nreal) {
   const DexSimConfig* cfg = &o->cfg;
   const DexHandModel* m = &o->model;
+  *nreal = 0;
   e->ncontact = 0;
   real co = cfg->contact_offset, rest = cfg->rest_offset;
   real zup[3] = {0, 0, 1};
@@ -485,6 +513,7 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
             m3v(pw, Rb, pl); v3add(pw, pw, e->box_pos);
             m3v(nw, Rb, nl);
             push_contact(e, 1, c, s, pw, nw, gr - rest, mu_hb);
+            (*nreal)++;
           }
         }
       }
@@ -492,8 +521,9 @@ static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
     const real* ends[2] = {e0, e1};
     for (int s = 0; s < 2; s++) {
       real zl = ends[s][2] - r;
-      if (zl < co) { real p[3] = {ends[s][0], ends[s][1], zl}; push_contact(e, 0, c, s, p, zup, zl - rest, mu_hg); }
+      if (zl < co) { real p[3] = {ends[s][0], ends[s][1], zl}; push_contact(e, 0, c, s, p, zup, zl - rest, mu_hg); (*nreal)++; }
     }
+    if (limit_rows && k < 15 && k % 3 == 2) push_limit_rows(o, e, k / 3);   /* behind the finger's three capsules */
   }
 }
 
@@ -537,19 +567,21 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
   for (int k = 0; k < K; k++) {
     OrcContact* c = &e->contact[k];
     real dir[3][3];
-    v3cpy(dir[0], c->n);
-    tangent_basis(c->n, dir[1], dir[2]);
+    memset(dir, 0, sizeof dir);
+    if (c->type != 3) { v3cpy(dir[0], c->n); tangent_basis(c->n, dir[1], dir[2]); }
     for (int r = 0; r < 3; r++) {
       real* Jr = J[3 * k + r];
       real* Yr = Y[3 * k + r];
       memset(Jr, 0, sizeof(real) * NV);
-      if (c->type != 2) {
+      if (c->type == 3) {   /* joint-limit row: J = +-e_j, one row (rows 1, 2 stay empty: 1/D = 0 below, mu = 0) */
+        if (r == 0) Jr[6 + 4 * c->finger + c->cap] = c->side ? (real)-1 : (real)1;
+      } else if (c->type != 2) {
         for (int j = m->cap_parent[c->cap]; j >= 0; j = joint_parent(j)) {
           real jv[3]; jac_col(m, &fk, j, c->p, jv);
           Jr[j] = v3dot(dir[r], jv);
         }
       }
-      if (c->type != 0) {
+      if (c->type == 1 || c->type == 2) {
         real sgn = c->type == 2 ? (real)1 : (real)-1, rb[3], rxd[3];
         v3sub(rb, c->p, e->box_pos);
         v3cross(rxd, rb, dir[r]);
@@ -560,7 +592,7 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
       for (int i = 0; i < 3; i++) { Yr[26 + i] = Jr[26 + i] * inv_m; Yr[29 + i] = Jr[29 + i] * inv_I; }
       real D = 0;
       for (int i = 0; i < NV; i++) D += Jr[i] * Yr[i];
-      Dinv[3 * k + r] = 1 / (D + (real)1e-9);
+      Dinv[3 * k + r] = (c->type == 3 && r > 0) ? 0 : 1 / (D + (real)1e-9);
       lam[3 * k + r] = 0;
     }
     cbias[k] = c->gap > 0 ? c->gap / h : -minr(-c->gap * cfg->erp / h, cfg->max_depenetration_velocity);
@@ -593,10 +625,10 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
                                             * entries when there are more than 12 (at most 12 hand blocks) */
     for (int k = 0; k < K; k++) {
       OrcContact* c = &e->contact[k];
-      fng[k] = c->type == 2 ? -1 : (m->cap_parent[c->cap] >= 6 ? (m->cap_parent[c->cap] - 6) / 4 : -1);
+      fng[k] = c->type == 2 ? -1 : (c->type == 3 ? c->finger : (m->cap_parent[c->cap] >= 6 ? (m->cap_parent[c->cap] - 6) / 4 : -1));
       blk[k] = c->type == 2 ? 12 : jh++ / run;
       cntb[blk[k]]++;
-      if (c->type != 0) boxb[blk[k]] = 1;
+      if (c->type == 1 || c->type == 2) boxb[blk[k]] = 1;
       if (fng[k] >= 0) fb[fng[k]][blk[k]] = 1;
     }
     int nB = 0, nX = 0, nF[5];
@@ -636,7 +668,7 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
       for (int i = NJ; i < NV; i++) Ys[row][i] = (real)nX * Y[row][i];
       real D = 0;
       for (int i = 0; i < NV; i++) D += J[row][i] * Ys[row][i];
-      Dinv[row] = 1 / (D + (real)1e-9);
+      Dinv[row] = (e->contact[row / 3].type == 3 && row % 3 > 0) ? 0 : 1 / (D + (real)1e-9);
     }
     for (int it = 0; it < cfg->num_position_iterations; it++) {
       real dsum[NV];
@@ -681,6 +713,7 @@ static void substep(const Oracle* o, OrcEnv* e, real h, int last) {
     for (int k = 0; k < K; k++) {
       OrcContact* c = &e->contact[k];
       real dir[3][3], F[3] = {0, 0, 0};
+      if (c->type == 3) continue;   /* a joint-limit reaction is a joint torque, not a force on a body */
       v3cpy(dir[0], c->n);
       tangent_basis(c->n, dir[1], dir[2]);
       for (int r = 0; r < 3; r++) v3axpy(F, lam[3 * k + r] / h, dir[r]);
@@ -1188,7 +1221,7 @@ void orc_physics_step(void* h) {
   double kc = 0, kh = 0;
   for (int i = 0; i < o->n; i++) {
     kc += o->env[i].ncontact;
-    for (int k = 0; k < o->env[i].ncontact; k++) kh += o->env[i].contact[k].type != 2;
+    for (int k = 0; k < o->env[i].ncontact; k++) kh += o->env[i].contact[k].type < 2;   /* (joint-limit rows are not contacts) */
   }
   o->stats[DEXSIM_STAT_MEAN_CONTACTS] = (float)(kc / o->n);
   o->stats[DEXSIM_STAT_MEAN_HAND_CONTACTS] = (float)(kh / o->n);

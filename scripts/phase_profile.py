@@ -71,6 +71,12 @@ for wv in range(7):
         print("wave 0, slowest workgroup: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(names, slow)))
         print("wave 0, publish stamp over workgroups: min %d  median %d  p90 %d  max %d" % (st[:, 6].min(), np.median(st[:, 6]), np.percentile(st[:, 6], 90), st[:, 6].max()))
 
+if "DBG_SWEEP" in os.environ.get("DEXSIM_EXTRA_DEFS", ""):   # pass 2 of the sweeps, every wave (rows 400 + 8 wave + i)
+    print("pass 2 of the sweeps, per wave (median workgroup): start | own work done | first barrier passed | reduction done | second barrier passed")
+    for wv in range(7):
+        ss = np.median(np.array([[crow[400 + wv * 8 + k, e] for k in range(5)] for e in lanes]), axis=0)
+        print(f"  wave {wv}: start {int(ss[0])}  work +{int(ss[1]-ss[0])}  B1 at {int(ss[2])} (+{int(ss[2]-ss[1])})  reduce +{int(ss[3]-ss[2])}  B2 at {int(ss[4])} (+{int(ss[4]-ss[3])})")
+
 # k_post: per-wave stamps after phase A (helper tasks / wave-0 loads), phase B (wave-0 logic), the row flush and the
 # obs_buf flush; then wave 0's logic split (relative to the start of phase B)
 core.run_stage(_abi.STAGE["POST"])

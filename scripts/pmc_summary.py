@@ -60,5 +60,29 @@ for rec in latest.values():               # template variants of one kernel: mea
     rec["fetch_kb"] /= rec["variants"]
     rec["write_kb"] /= rec["variants"]
     del rec["variants"]
+# instruction-issue counters (scripts/pmc_issue.sh): mean per k_physics4<false> launch, headline regime and the SETTLED contact-rich
+# regime (the last 100 launches of scripts/contact_regime.py ... contact-only: steps 121-220 after the teleport)
+issue = {"num_envs": num_envs}
+for tag, key, last in (("h", "headline", None), ("c", "contact_settled", 100)):
+    rec = {}
+    for part in ("1", "2"):
+        f = glob.glob(os.path.join(src, f"issue_{tag}{part}", "**", "*counter_collection.csv"), recursive=True)
+        if not f:
+            continue
+        d = pd.read_csv(f[0])
+        d = d[d["Kernel_Name"].str.contains("k_physics4<false>", regex=False) | d["Kernel_Name"].str.contains("k_physics4<(bool)0>", regex=False)]
+        for cname, g in d.groupby("Counter_Name"):
+            g = g.sort_values("Dispatch_Id")
+            vals = g["Counter_Value"].values
+            if last:
+                vals = vals[-last:]
+            rec[cname] = float(vals.mean())
+            rec["launches"] = int(len(vals))
+    if rec:
+        issue[key] = rec
+if len(issue) > 1:
+    latest["issue"] = issue
+    with open(os.path.join(dst, "issue_counters.json"), "w") as fh:
+        json.dump(issue, fh, indent=1, sort_keys=True)
 json.dump(latest, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_latest.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(latest, indent=1))

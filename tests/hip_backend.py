@@ -43,7 +43,10 @@ class HipBackend:
 
     def contacts(self, env):
         k = int(self.get("ncontact")[0, env])
-        g = self.get("cgeom")[:, env].reshape(_abi.KMAX, 8)[:k]
+        # cgeom is a quad-layout field: list entry kk = quads 2 kk, 2 kk + 1 of [quad][env][4] (p.xyz n.x | n.yz gap mu)
+        off, rows, _ = self.core.fields["cgeom"]
+        quads = self.core.arena[off: off + rows * self.core.NS].view(rows // 4, self.core.NS, 4)
+        g = quads[:, env].detach().cpu().numpy().astype(np.float64).reshape(_abi.KMAX, 8)[:k]
         code = self.get("ccode")[:, env][:k].astype(int)
         out = np.zeros((k, 10))
         out[:, :8] = g

@@ -1010,10 +1010,12 @@ def test_config3_headline_workload_as_itself_through_the_synchronous_reset():
         assert hb.stats()[16] == o.stats()[16] and hb.stats()[17] == (2 if do.any() else 1)
         if do.any():
             sync_steps.append((t, int(do.sum())))
-    assert sync_steps == [(199, n)], sync_steps               # the synchronous all-env reset, once, at control step 200
+    # the synchronous all-env reset, exactly once: reset() evaluates the observations (and with them the stage clock) twice
+    # (dexhand_base.py:805-838), so stage 1's 4 s run out in control step 199
+    assert sync_steps == [(198, n)], sync_steps
     errs = np.stack(errs)
     assert np.median(errs) < 1e-4 and np.percentile(errs, 99.9) < 5e-3, (np.median(errs), np.percentile(errs, 99.9), errs.max())
-    assert np.median(errs[200:]) < 1e-4                        # the new episodes start from the same Philox samples
+    assert np.median(errs[199:]) < 1e-4                        # the new episodes start from the same Philox samples
     assert (hb.get("reset_count") == o.get("reset_count")).all() and int(o.get("reset_count").min()) == 2
     fr_h, fr_o = hb.get("failure_reason"), o.get("failure_reason")
     assert (fr_h == fr_o).all()
@@ -1137,3 +1139,40 @@ def test_static_contact_test_box_of_the_reference_harness():
     tip_z = od["fingertip_poses_world"][:, 7 * 2 + 2]
     assert float((tip_z - (0.1 + 0.007)).abs().max()) < 4e-3   # tip sphere (r = 7 mm) rests on the box top z = 0.1
     env.close()
+
+
+@pytest.mark.gpu
+def test_obs_dict_policy_mode_serves_policy_keys_from_obs_buf():
+    """env.obsDict = 'policy' (dexsim_set_obs_dict_mode): the step no longer writes the 392 SoA rows behind
+    get_observations_dict(); obs_dict serves the policy keys as views of obs_buf and refuses every other key of the reference's
+    obs_dict with a message that says how to get it.  Everything the step returns is bit-identical to the default mode."""
+    import torch
+    from dexrobot_isaac_amd import default_cfg, make_env
+    n = 130
+    envs = []
+    for mode in ("all", "policy"):
+        cfg = default_cfg("BlindGrasping")
+        cfg["env"]["episodeLength"] = 9
+        cfg["env"]["obsDict"] = mode
+        envs.append(make_env("BlindGrasping", n, "cuda:0", "cuda:0", 0, cfg=cfg))
+    full, pol = envs
+    full.reset(), pol.reset()
+    g = torch.Generator().manual_seed(3)
+    for t in range(14):
+        a = (2 * torch.rand(n, 18, generator=g) - 1).cuda()
+        of, rf, df, _ = full.step(a)
+        op, rp, dp, ip = pol.step(a)
+        assert torch.equal(of, op) and torch.equal(rf, rp) and torch.equal(df, dp)
+    od_f, od_p = full.get_observations_dict(), pol.get_observations_dict()
+    assert set(od_p) == set(pol.task_cfg["policy_observation_keys"])
+    for k in od_p:
+        assert torch.equal(od_p[k], od_f[k]), k
+    assert torch.equal(torch.cat([od_p[k] for k in pol.task_cfg["policy_observation_keys"]], dim=1), pol.obs_buf)
+    with pytest.raises(KeyError, match="obsDict"):
+        od_p["all_finger_dof_pos"]
+    assert float(pol._core.field("obs_all").abs().max()) == 0.0 and float(full._core.field("obs_all").abs().max()) > 0.0
+    assert float(ip["reward_components"]["total"].abs().max()) > 0        # extras are unaffected
+    with pytest.raises(RuntimeError, match="obsDict"):
+        pol.action_processor.set_pre_action_rule(lambda prev, state: prev)
+        pol.step(a)
+    full.close(), pol.close()
