@@ -412,7 +412,7 @@ def main():
             ncs = core.field("ncontact").float()
             code = core.field("ccode")
             kidx = torch.arange(code.shape[0], device=device)[:, None]
-            hand = float((((code & 3) != 2) & (kidx < core.field("ncontact"))).sum().item()) / N
+            hand = float((((code & 3) < 2) & (kidx < core.field("ncontact"))).sum().item()) / N
             # BASELINE sub-metric "contact-solve HBM %" on the PRODUCTION kernel: phases 3 + 4 of the general contact path (contact rows
             # + the block solver's 17 passes) as a fraction of the launch, from the kernel's own s_memtime stamps, times the launch
             # time between HIP events; settled contact-rich state, hand contacts > 0.  Next to it the bound that actually binds:

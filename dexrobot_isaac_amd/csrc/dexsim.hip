@@ -500,6 +500,8 @@ int dexsim_set_dof_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void
 int dexsim_set_root_state_indexed(dexsim_t h, const int64_t* env_ids, int k, void* stream) { return ingest(h, env_ids, k, 1, stream); }
 
 static int launch_stage(dexsim_t h, int stage, void* stream) {
+  if (h->cfg.joint_limit_rows && (stage == DEXSIM_STAGE_DYNAMICS || stage == DEXSIM_STAGE_SOLVE))
+    return fail(DEXSIM_ERR_ARG, "the un-fused k_dynamics / k_solve test kernels do not build joint-limit rows (joint_limit_rows): use the fused path");
   switch (stage) {
     case DEXSIM_STAGE_DYNAMICS: return launch_dynamics(h, 0, stream);
     case DEXSIM_STAGE_SOLVE: return launch_solve(h, 0, 1, stream);

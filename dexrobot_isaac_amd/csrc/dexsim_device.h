@@ -20,7 +20,7 @@
   /* dynamics -> contact-solve interface (one sub-step) */                                                  \
   X(float, jframe, 156) X(float, ufree, 32) X(float, fac_sinv, 21) X(float, fac_finv, 60)                   \
   X(float, fac_g, 120) X(int, ncontact, 1) X(float, cgeom, DEXSIM_KMAX * 8) X(int, ccode, DEXSIM_KMAX)      \
-  X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28 + 4) X(float, cbias, DEXSIM_KMAX) X(float, clam, DEXSIM_KMAX * 3) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * 15 * 9)                                         \
+  X(float, crow, DEXSIM_KMAX * 3 * 28) X(float, crowq, DEXSIM_KMAX * 3 * 28 + 4) X(float, cbias, DEXSIM_KMAX) X(float, clam, DEXSIM_KMAX * 3) X(float, chdr, DEXSIM_KMAX * 8) X(float, cstage, 6 * NP_STAGE * 9)                                         \
   /* warm-start cache: per contact key one float4 (impulses of the previous sub-step, tag), [key][env][4]; wgen = the env's sub-step generation */ \
   X(float, wlam, DEXSIM_NWKEY * 4) X(int, wgen, 1) X(int, csplit, 1)                                         \
   /* L2 state (ActionProcessor / ObservationEncoder / task / RewardCalculator / TerminationManager) */      \
@@ -54,7 +54,8 @@ struct Arena {
 #define JFRAME_FQ0 9   /* first quad of finger 0's joint frames in jframe (36 base-joint words come first) */
 // the manifold (cgeom: 2 quads per list entry: p.xyz n.x | n.yz gap mu) and the narrowphase staging blocks (cstage: 2 quads per staged
 // contact, 6 waves x 15; their codes as plain rows behind the 180 quads) are FQ fields too
-#define CSTAGE_CODE0 720
+#define NP_STAGE 20                     /* staged entries per narrowphase wave: <= 12 contacts of its three capsules + <= 8 joint-limit rows */
+#define CSTAGE_CODE0 (6 * NP_STAGE * 8)
 
 #define CROW_W 28 /* words per contact row: t6 jf4 St6 Fj4 d3 rxd3 Dinv pad */
 // crowq: the rows of streamed hand contacts in the quad layout of the LDS row store ([quad][env] of float4, 21 quads per

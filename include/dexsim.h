@@ -245,10 +245,10 @@ typedef struct DexSimConfig {
   float box_fixed_pos[3];
   /* Joint limits as unilateral solver rows (round 3; the reference's limits are PhysX articulation limits, dof_props lower / upper,
    * tensor_manager.py:547-554).  With joint_limit_rows != 0 every finger joint within joint_limit_margin (rad) of a limit gets a
-   * one-row speculative constraint (J = +-e_j, gap = distance to the limit, no friction) in the contact solver -- in envs that have
-   * at least one hand contact in the sub-step: without contact forces the PD drive cannot push a joint across a limit its own
-   * target respects, and the position clamp behind the integration stays as the safety net in every case.  List order: a
-   * finger's limit rows follow that finger's contacts; they count against DEXSIM_KMAX. */
+   * one-row speculative constraint (J = +-e_j, gap = distance to the limit, no friction) in the contact solver -- for the fingers
+   * that have at least one contact in the sub-step: without contact forces the PD drive cannot push a joint across a limit its
+   * own target respects, and the position clamp behind the integration stays as the safety net in every case.  List order: a
+   * finger's limit rows follow that finger's contacts; they count against DEXSIM_KMAX; each is a solver block of its own. */
   int   joint_limit_rows;
   float joint_limit_margin;
 } DexSimConfig;

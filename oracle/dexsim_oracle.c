@@ -448,17 +448,11 @@ static inline real seg_box_dfdt(const real* a, const real* d, real t, const real
   return g;
 }
 
-static void collide_pass(const Oracle* o, OrcEnv* e, const FK* fk, int limit_rows, int* nreal);
 static void collide(const Oracle* o, OrcEnv* e, const FK* fk) {
-  /* joint-limit rows exist only in envs with at least one hand contact (counted before the list is cut at KMAX) */
-  int nreal = 0;
-  collide_pass(o, e, fk, o->cfg.joint_limit_rows, &nreal);
-  if (o->cfg.joint_limit_rows && nreal == 0) collide_pass(o, e, fk, 0, &nreal);
-}
-static void collide_pass(const Oracle* o, OrcEnv* e, const FK* fk, int limit_rows, int* nreal) {
   const DexSimConfig* cfg = &o->cfg;
   const DexHandModel* m = &o->model;
-  *nreal = 0;
+  const int limit_rows = cfg->joint_limit_rows;
+  int nreal_v = 0, *nreal = &nreal_v;   /* contacts found for the current finger (before the list is cut at KMAX) */
   e->ncontact = 0;
   real co = cfg->contact_offset, rest = cfg->rest_offset;
   real zup[3] = {0, 0, 1};
@@ -523,7 +517,10 @@ static void collide_pass(const Oracle* o, OrcEnv* e, const FK* fk, int limit_row
       real zl = ends[s][2] - r;
       if (zl < co) { real p[3] = {ends[s][0], ends[s][1], zl}; push_contact(e, 0, c, s, p, zup, zl - rest, mu_hg); (*nreal)++; }
     }
-    if (limit_rows && k < 15 && k % 3 == 2) push_limit_rows(o, e, k / 3);   /* behind the finger's three capsules */
+    if (k < 15 && k % 3 == 2) {   /* behind the finger's three capsules: its joint-limit rows, if the finger touches anything */
+      if (limit_rows && *nreal > 0) push_limit_rows(o, e, k / 3);
+      *nreal = 0;
+    }
   }
 }
 

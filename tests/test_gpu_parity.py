@@ -1176,3 +1176,75 @@ def test_obs_dict_policy_mode_serves_policy_keys_from_obs_buf():
         pol.action_processor.set_pre_action_rule(lambda prev, state: prev)
         pol.step(a)
     full.close(), pol.close()
+
+
+@pytest.mark.gpu
+def test_joint_limit_rows_match_oracle():
+    """sim.dexsim_joint_limit_rows on the HIP path (general contact path: rows staged behind a finger's contacts, type-3 list
+    entries, one-row blocks, warm-start slots 88 + ...) against the oracle: teacher-forced sub-steps from states in which many
+    finger joints sit within the margin of a limit while the hand touches box and ground.  Lists identical entry by entry
+    (type, capsule / joint level, gap), state to the usual teacher-forced tolerances, the limit rows' impulses to 2e-3 abs /
+    2 % rel, statistics (rows are not contacts) exact; plus free-running control steps through dexsim_step."""
+    from oracle.oracle import Oracle
+    from tests.hip_backend import HipBackend
+    n = 256
+    sc, model = _mk("BlindGrasping", n, **{"sim.dexsim_joint_limit_rows": True})
+    assert int(sc.joint_limit_rows) == 1
+    ms = model.to_struct()
+    o, hb = Oracle(sc, ms), HipBackend(sc, ms)
+    rng = np.random.default_rng(17)
+    st = _random_state(rng, model, n)
+    near = rng.random((20, n)) < 0.4                      # 40 % of the finger joints on / next to a limit
+    side = rng.random((20, n)) < 0.7
+    lo, hi = model.lo[6:, None], model.hi[6:, None]
+    off = rng.uniform(0.0, 0.012, (20, n))
+    st["q"][6:] = np.where(near, np.where(side, lo + off, hi - off), st["q"][6:])
+    st["targets"][6:] = np.where(near, st["q"][6:] - np.where(side, 0.2, -0.2), st["targets"][6:])    # PD pushes into the stop
+    for k, v in st.items():
+        o.set(k, v)
+        hb.set(k, v)
+    rows_seen = 0
+    for sub in range(3):
+        o.substep(last=True)
+        hb.substep(last=True)
+        nc_o, nc_h = o.get("ncontact")[0], hb.get("ncontact")[0]
+        assert (nc_o == nc_h).all(), f"list length differs in {(nc_o != nc_h).sum()} envs at sub-step {sub}"
+        for e in range(0, n, 4):
+            co, ch = o.contacts(e), hb.contacts(e)
+            assert (co[:, 8] == ch[:, 8]).all() and (co[co[:, 8] != 2, 9] == ch[co[:, 8] != 2, 9]).all()
+            np.testing.assert_allclose(ch[:, :8], co[:, :8], atol=2e-6)
+            rows_seen += int((co[:, 8] == 3).sum())
+        np.testing.assert_allclose(hb.get("q"), o.get("q"), atol=2e-4)
+        np.testing.assert_allclose(hb.get("qd"), o.get("qd"), atol=5e-3, rtol=2e-3)
+        np.testing.assert_allclose(hb.get("cforce"), o.get("cforce"), atol=5e-2, rtol=2e-2)
+        lam_h, tag_h, gen_h = hb.warm_cache()
+        lam_o, tag_o, gen_o = o.get("wlam"), o.get("wtag").astype(np.int64), o.get("wgen")[0].astype(np.int64)
+        vo, vh = (tag_o[88:] >> 3) == gen_o, (tag_h[88:] >> 3) == gen_h
+        assert (vo == vh).all() and (gen_o == gen_h).all()
+        lo3, lh3 = lam_o[88 * 3:].reshape(40, 3, n)[:, 0], lam_h[88 * 3:].reshape(40, 3, n)[:, 0]
+        np.testing.assert_allclose(lh3[vo], lo3[vo], atol=2e-3, rtol=2e-2)
+        for k in ("q", "qd", "box_pos", "box_quat", "box_lin", "box_ang"):
+            hb.set(k, o.get(k))
+    assert rows_seen > n // 4 and float(np.abs(lo3[vo]).max()) > 1e-3       # rows exist and some carry load
+    # free-running control steps through the production launch (dexsim_step), in-step resets included
+    sc2, model2 = _mk("BlindGrasping", 192, **{"sim.dexsim_joint_limit_rows": True, "env.episodeLength": 12})
+    ms2 = model2.to_struct()
+    o2, h2 = Oracle(sc2, ms2), HipBackend(sc2, ms2)
+    np.testing.assert_allclose(h2.reset(), o2.reset(), atol=2e-4)
+    for b in (o2, h2):                                      # hands low over their boxes: contacts from the first step on
+        q = b.get("q")
+        q[2] = -0.255
+        b.set("q", q); b.set("targets", q)
+    rng = np.random.default_rng(4)
+    errs, mism, hand_max = [], 0, 0.0
+    for t in range(16):
+        a = (0.3 * (2 * rng.random((192, 18)) - 1)).astype(np.float32)
+        oo, ro, do = o2.step(a)
+        oh, rh, dh = h2.step(a)
+        errs.append(np.abs(oh - oo).max(axis=1))
+        mism += int((do != dh.astype(bool)).sum())
+        assert h2.stats()[19] <= h2.stats()[18] and abs(h2.stats()[19] - o2.stats()[19]) < 0.05
+        hand_max = max(hand_max, float(o2.stats()[19]))
+    errs = np.stack(errs)
+    assert np.median(errs) < 1e-4 and np.percentile(errs, 99) < 5e-3 and mism <= 2, (np.median(errs), np.percentile(errs, 99), mism)
+    assert hand_max > 0.5                                   # (before the timeouts at step 11 send the hands back up)

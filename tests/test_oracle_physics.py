@@ -257,3 +257,72 @@ def test_warm_start_generation_wraps_without_losing_the_cache():
     tb, gb = b.get("wtag")[:, 0].astype(np.int64), int(b.get("wgen")[0, 0])
     assert ((tb >> 3) == gb).sum() == int(b.get("ncontact")[0, 0]) == 5 and tb.min() >= 0 and tb.max() < (1 << 30)
     assert np.linalg.norm(b.get("cforce")[:, 0].reshape(17, 3)[8]) > 20.0      # still the converged ~30 N press
+
+
+def _limit_cfg(rows, n=1, iters=16, f64=True):
+    cfg = default_cfg("BlindGrasping")
+    cfg["env"]["numEnvs"] = n
+    cfg["sim"]["dexsim_joint_limit_rows"] = rows
+    cfg["sim"]["physx"]["num_position_iterations"] = iters
+    sc, model = build_sim_config(cfg)
+    return Oracle(sc, model.to_struct(), f64=f64), model, sc
+
+
+def test_joint_limit_rows_option():
+    """sim.dexsim_joint_limit_rows (round 3, VERDICT missing #3): joint limits as unilateral rows of the contact solver -- for the
+    fingers that touch something, every joint within the margin of a limit gets a one-row speculative constraint (a block of its
+    own).  (a) Without contacts the option changes nothing, bit for bit.  (b) A straight middle finger pressed onto the box with
+    the hand tilted so that the contact force loads the PIP / DIP joints against their lower stops (lo = 0): the rows of
+    exactly those joints carry positive impulses, the joints sit ON the limit at rest (no clamp needed), rows of unloaded joints
+    carry none (complementarity); the list is 4 box/ground + 1 contact + the finger's 4 lower-limit rows; the rows are neither
+    contacts in the statistics nor forces on a body; 16 warm-started sweeps are within 15 % of the converged impulses."""
+    # (a) free space
+    a, _, _ = _limit_cfg(0, n=4)
+    b, _, _ = _limit_cfg(1, n=4)
+    a.reset(), b.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        act = (2 * rng.random((4, 18)) - 1).astype(np.float32)
+        oa, _, _ = a.step(act)
+        ob, _, _ = b.step(act)
+    np.testing.assert_array_equal(oa, ob)
+    # (b) the loaded stop
+    def run(rows, iters):
+        o, model, sc = _limit_cfg(rows, iters=iters)
+        o.set("box_pos", np.array([[0.0], [0.0], [0.0255]]))
+        q = np.zeros((26, 1))
+        q[4], q[0] = 0.4, 0.08
+        o.set("q", q)
+        tg = q.copy()
+        for _ in range(500):
+            tg[2] = max(tg[2, 0] - 0.001, -0.275)
+            o.set("targets", tg)
+            o.physics_step()
+        return o, model
+    o, model = run(1, 16)
+    oc, _ = run(1, 200)
+    K = int(o.get("ncontact")[0, 0])
+    con = o.contacts(0)
+    assert K == 9 and list(con[:, 8].astype(int)) == [2, 2, 2, 2, 1, 3, 3, 3, 3] and list(con[5:, 9].astype(int)) == [0, 1, 2, 3]
+    np.testing.assert_allclose(con[5:, 6], o.get("q")[14:18, 0] - model.lo[14:18], atol=1e-6)     # gap = distance to the lower limit
+    lam = o.get("wlam")[:, 0].reshape(-1, 3)
+    lamc = oc.get("wlam")[:, 0].reshape(-1, 3)
+    keys = [88 + (8 + l) * 2 for l in range(4)]                     # finger 2, joints 0..3, lower side
+    tag, gen = o.get("wtag")[:, 0].astype(int), int(o.get("wgen")[0, 0])
+    assert all(tag[k] >> 3 == gen for k in keys)
+    q, qd = o.get("q")[14:18, 0], o.get("qd")[14:18, 0]
+    loaded = lam[keys, 0] > 1e-4
+    assert list(loaded) == [False, True, True, True]                # spread joint unloaded; MCP flexion, PIP, DIP on their stops
+    assert np.abs(q[loaded] - model.lo[14:18][loaded]).max() < 1e-7 and np.abs(qd[loaded]).max() < 1e-6
+    assert (lam[keys, 1:] == 0).all() and (lam[keys, 0] >= 0).all()
+    assert np.abs(lam[keys, 0] - lamc[keys, 0]).max() < 0.15 * lamc[keys, 0].max()
+    assert float(o.stats()[19]) == 1.0 and float(o.stats()[18]) == 9.0     # mean hand contacts: the one contact; list length 9
+    cf = o.get("cforce")[:, 0].reshape(17, 3)
+    assert np.linalg.norm(cf[8]) > 100 and np.abs(np.delete(cf, [8, 16], axis=0)).max() == 0.0   # only the distal link and the box feel a force
+    # fp32 oracle agrees with fp64 here too
+    o32, _, _ = _limit_cfg(1, f64=False)
+    for f in ("q", "qd", "targets", "box_pos", "box_quat", "box_lin", "box_ang", "wlam", "wtag", "wgen"):   # (state + warm-start cache)
+        o32.set(f, o.get(f))
+    o64 = o
+    o32.physics_step(), o64.physics_step()
+    np.testing.assert_allclose(o32.get("q"), o64.get("q"), atol=2e-5)
