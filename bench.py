@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--obs-dict", default="policy", choices=["policy", "all"],
                     help="policy (default): only obs_buf is written, as in a training loop (env.obsDict = policy); all: every step also "
                          "materialises the 392 rows behind get_observations_dict() (the product's default for API parity)")
+    ap.add_argument("--joint-limit-rows", action="store_true", help="sim.dexsim_joint_limit_rows: joint limits as unilateral solver rows (option; see DESIGN.md section 4)")
     ap.add_argument("--substeps", type=int, default=None, help="sim.substeps (default: the task's 4; 32 = cfg/physics/accurate.yaml)")
     ap.add_argument("--iterations", type=int, default=None, help="sim.physx.num_position_iterations (default 16; 32 = accurate.yaml)")
     return ap.parse_args()
@@ -117,6 +118,8 @@ def training_like(args, N, device, gen, steps=200, warm=60):
     cfg = default_cfg("BlindGrasping")
     cfg["task"]["hand_translation_range"] = 0.40
     cfg["env"]["obsDict"] = args.obs_dict
+    if args.joint_limit_rows:
+        cfg["sim"]["dexsim_joint_limit_rows"] = True
     dev = str(device)
     env = make_env("BlindGrasping", N, dev, dev, 0, cfg=cfg)
     core = env._core
@@ -192,6 +195,8 @@ def main():
         cfg["env"]["numEnvs"] = n
         if args.control_mode:
             cfg["task"]["controlMode"] = args.control_mode
+        if args.joint_limit_rows:
+            cfg["sim"]["dexsim_joint_limit_rows"] = True
         if args.substeps:
             cfg["sim"]["substeps"] = args.substeps
         if args.iterations:
@@ -222,21 +227,24 @@ def main():
     core.reset()
     rollout = RolloutBuffer(args.horizon, N, sc.num_obs, device, mode=args.gather) if (world > 1 or args.rollout) else None
 
-    pending = []
+    pending, last_handle = [], [None]
 
     def run(k):
         for i in range(k):
             if rollout is not None:
-                rollout.sink(core)           # this step's obs / rew / done land in the rollout slot: no copy kernels
+                rollout.sink(core)           # this step's obs / rew / done (+ statistics block) land in the rollout slot: no copy kernels
             core.step(actions[i % n_act])
             if rollout is not None:
                 if rollout.full():
-                    # RCCL gather over xGMI, once per rollout, overlapped with the next rollout's simulation
+                    # RCCL gather over xGMI (+ the all-reduce of the statistics rows), once per rollout, overlapped with the next
+                    # rollout's simulation
                     pending.append(rollout.gather_async())
                     if len(pending) > 1:
-                        pending.pop(0)()     # the previous rollout's gather must have landed by now
+                        last_handle[0] = pending.pop(0)
+                        last_handle[0]()     # the previous rollout's gather must have landed by now
         while pending:
-            pending.pop(0)()
+            last_handle[0] = pending.pop(0)
+            last_handle[0]()
 
     run(args.warmup)
     resets0 = float(core.field("reset_count").sum().item())
@@ -264,6 +272,7 @@ def main():
 
     collective = None
     if world > 1:
+        gstats = last_handle[0].stats() if last_handle[0] is not None else None     # whole-population statistics of the last rollout (all ranks)
         # the end-of-rollout collective on its own (not overlapped), next to the simulation time of one rollout
         tms = []
         for _ in range(5):
@@ -278,6 +287,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         per_rank_mb = args.horizon * N * (sc.num_obs * 4 + 4 + 1) / 1e6
         collective = {"mode": args.gather, "collective_ms": float(tt.item()),
+                      "global_stats_last_rollout": None if gstats is None else {
+                          k: float(gstats[k].mean()) for k in ("success_rate", "failure_rate", "timeout_rate", "num_resets", "mean_contacts")},
                       "simulation_ms_per_rollout": dt / args.steps * 1e3 * args.horizon,
                       "payload_mb_per_rank": per_rank_mb, "rccl_ranks": dist.get_world_size(),
                       "note": "collective_ms = blocking gather alone (median of 5, max over ranks); in the timed region it is "
@@ -292,8 +303,11 @@ def main():
         # each single launch is NOT used: the events' release/acquire fences make the kernel start from a cold L2.
         t_step = ev0.elapsed_time(ev1) * 1e3 / args.steps
         t_sub = core.time_stage(_abi.STAGE["SUBSTEP"], 50)     # a single sub-step (dynamics + solve + integrate + publish) as its own launch
-        t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)     # the same sweeps as a stand-alone kernel
-        t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)
+        if args.joint_limit_rows:      # (the un-fused test kernels do not build joint-limit rows)
+            t_solve = t_dyn = float("nan")
+        else:
+            t_solve = core.time_stage(_abi.STAGE["SOLVE"], 50)     # the same sweeps as a stand-alone kernel
+            t_dyn = core.time_stage(_abi.STAGE["DYNAMICS"], 50)
         t_post = core.time_stage(_abi.STAGE["POST"], 20)
         t_pub = core.time_stage(_abi.STAGE["PUBLISH"], 20)
         b_sub = (632.0 + 204.0) * N                    # q, qd, targets, box in; q, qd, box out; cforce (last sub-step)
@@ -331,7 +345,7 @@ def main():
                        "contact_solver": "warm-started block-parallel PGS with mass splitting (HIP: csrc/dexsim_physics.hip.inc, phases 3-4 of substep_body)",
                        "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
                        "rollout_gather_mode": args.gather if world > 1 else None,
-                       "domain_randomisation": bool(args.dr)},
+                       "domain_randomisation": bool(args.dr), "joint_limit_rows": bool(args.joint_limit_rows)},
             "resets_per_step": resets / args.steps,
             # the headline regime's contact set: random actions from the spawn pose never bring a finger to the box, so
             # these are the box's corners on the ground (see contact_rich for the regime the solver exists for)

@@ -258,6 +258,9 @@ int dexsim_create(const DexSimConfig* cfg, const DexHandModel* model, int device
     c.mass = model->mass[j]; c.kp = model->kp[j]; c.kd = model->kd[j]; c.armature = model->armature[j];
     c.lo = model->lo[j]; c.hi = model->hi[j];
   }
+  hp.inertia_diag = 1;
+  for (int j = 6; j < DEXSIM_NJ; j++)
+    for (int i = 3; i < 6; i++) if (model->inertia[j][i] != 0.f) hp.inertia_diag = 0;
   HIP_TRY(hipMalloc(&h->d_params, sizeof(DevParams)));
   HIP_TRY(hipMemcpy(h->d_params, &hp, sizeof(DevParams), hipMemcpyHostToDevice));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

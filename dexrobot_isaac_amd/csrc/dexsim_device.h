@@ -79,6 +79,7 @@ struct DevParams {
   // revolute): world axes A_j, the constant part Oc_j of the origin of joint frame j, orientation of frame 3 at q3 = 0
   float base_A[4][3], base_Oc[4][3], base_Q3z[4];
   unsigned obs_div_magic; // ceil(2^32 / num_obs): idx / num_obs == umulhi(idx, magic) for idx < 2^16 (obs_buf flush)
+  int inertia_diag;  // every finger link's inertia is diagonal in its joint frame (host-side check of the model): rotate_inertia_diag
   float hand_reach;  // bound on |x - o5| over every point x of every hand capsule, for any joint configuration
                      // (o5 = origin of the palm joint frame): the hand-level broadphase of k_substep
   int obs_col_row[DEXSIM_OBS_ALL_DIM]; // obs_buf column -> obs_all row (flattened policy_observation_keys)
@@ -178,6 +179,15 @@ DI S6 rotate_inertia(const M3& R, const float* s /*xx yy zz xy xz yz*/) {
     for (int k = 0; k < 3; k++) T[3 * r + k] = R.m[3 * r] * Il[k] + R.m[3 * r + 1] * Il[3 + k] + R.m[3 * r + 2] * Il[6 + k];
   auto e = [&](int r, int k) { return T[3 * r] * R.m[3 * k] + T[3 * r + 1] * R.m[3 * k + 1] + T[3 * r + 2] * R.m[3 * k + 2]; };
   return {e(0, 0), e(1, 1), e(2, 2), e(0, 1), e(0, 2), e(1, 2)};
+}
+// R * diag(a, b, c) * R^T: link inertias given in their principal frame (DevParams::inertia_diag: every link of the model) -- 27
+// instead of 45 multiply-adds, four times per finger wave and sub-step
+DI S6 rotate_inertia_diag(const M3& R, const float* s /*xx yy zz*/) {
+  const float a0 = s[0] * R.m[0], a3 = s[0] * R.m[3], a6 = s[0] * R.m[6];
+  const float b1 = s[1] * R.m[1], b4 = s[1] * R.m[4], b7 = s[1] * R.m[7];
+  const float c2 = s[2] * R.m[2], c5 = s[2] * R.m[5], c8 = s[2] * R.m[8];
+  return {a0 * R.m[0] + b1 * R.m[1] + c2 * R.m[2], a3 * R.m[3] + b4 * R.m[4] + c5 * R.m[5], a6 * R.m[6] + b7 * R.m[7] + c8 * R.m[8],
+          a0 * R.m[3] + b1 * R.m[4] + c2 * R.m[5], a0 * R.m[6] + b1 * R.m[7] + c2 * R.m[8], a3 * R.m[6] + b4 * R.m[7] + c5 * R.m[8]};
 }
 // parallel-axis term  m (|d|^2 E - d d^T)
 DI S6 pa(float m, V3 d) {

@@ -1233,8 +1233,14 @@ def test_joint_limit_rows_match_oracle():
     np.testing.assert_allclose(h2.reset(), o2.reset(), atol=2e-4)
     for b in (o2, h2):                                      # hands low over their boxes: contacts from the first step on
         q = b.get("q")
+        q[:6] = 0.0
         q[2] = -0.255
-        b.set("q", q); b.set("targets", q)
+        q[6:] = 0.004                                       # fingers straight, next to their lower stops
+        apt = b.get("active_prev_targets")
+        apt[:] = 0.004
+        apt[:6] = q[:6]
+        b.set("q", q); b.set("targets", q); b.set("active_prev_targets", apt)
+        b.set("box_pos", np.array([[0.0], [0.0], [0.0255]]) + 0 * q[:3])
     rng = np.random.default_rng(4)
     errs, mism, hand_max = [], 0, 0.0
     for t in range(16):
