@@ -1254,3 +1254,37 @@ def test_joint_limit_rows_match_oracle():
     errs = np.stack(errs)
     assert np.median(errs) < 1e-4 and np.percentile(errs, 99) < 5e-3 and mism <= 2, (np.median(errs), np.percentile(errs, 99), mism)
     assert hand_max > 0.5                                   # (before the timeouts at step 11 send the hands back up)
+
+
+@pytest.mark.gpu
+def test_make_env_product_path_tight_without_contacts():
+    """the only oracle comparison that went through make_env().step() carried bifurcation headroom
+    (obs 2e-3, reward 2e-2) because fingers touch things in BlindGrasping.  The same product surface without contacts --
+    BaseTask, position_delta, random actions, in-step resets by time-out -- at parity tolerances: obs 1e-4 abs, reward 1e-4
+    abs + 1e-5 rel, done flags / extras masks / rates exact, 40 control steps."""
+    import torch
+    from dexrobot_isaac_amd import default_cfg, make_env
+    from oracle.py_backend import OracleCore
+    n = 200
+    cfg = default_cfg("BaseTask")
+    cfg["env"]["episodeLength"] = 17
+    env = make_env("BaseTask", n, "cuda:0", "cuda:0", 0, cfg=cfg)
+    ref = make_env("BaseTask", n, "cpu", "cpu", 0, cfg=cfg, _core_factory=OracleCore)
+    np.testing.assert_allclose(env.reset().cpu().numpy(), ref.reset().numpy(), atol=1e-5)
+    g = torch.Generator().manual_seed(8)
+    resets = 0
+    for t in range(40):
+        a = 2 * torch.rand(n, 18, generator=g) - 1
+        og, rg, dg, ig = env.step(a.cuda())
+        orr, rr, dr, ir = ref.step(a)
+        np.testing.assert_allclose(og.cpu().numpy(), orr.numpy(), atol=1e-4)
+        np.testing.assert_allclose(rg.cpu().numpy(), rr.numpy(), atol=1e-4, rtol=1e-5)
+        assert (dg.cpu() == dr).all()
+        for k in ("success", "failure", "timeout"):
+            assert (ig[k].cpu() == ir[k]).all()
+        assert float(ig["timeout_rate"]) == float(ir["timeout_rate"]) and float(ig["failure_rate"]) == float(ir["failure_rate"])
+        for k, v in ir["reward_components"].items():
+            np.testing.assert_allclose(ig["reward_components"][k].cpu().numpy(), v.numpy(), atol=1e-4, rtol=1e-5, err_msg=k)
+        resets += int(dr.sum())
+    assert resets >= 2 * n
+    env.close()
