@@ -102,7 +102,8 @@ def test_teacher_forced_substep_matches_oracle(task, fused):
     np.testing.assert_allclose(hb.get("hand_vel"), o.get("hand_vel"), atol=2e-5)
 
 
-@pytest.mark.parametrize("z_range", [(-0.1, 0.2), (-0.36, -0.30), (-0.43, -0.38)], ids=["hand_clear", "sphere_fails_capsules_clear", "touching"])
+@pytest.mark.parametrize("z_range", [(-0.1, 0.2), (-0.36, -0.30), (-0.43, -0.38), (-0.222, -0.216)],
+                         ids=["hand_clear", "sphere_fails_capsules_clear", "touching", "capsules_near_nothing_touches"])
 def test_broadphase_regimes_match_oracle(z_range):
     """The sub-step kernel has three regimes per workgroup -- hand bounding sphere clear (early box solve), sphere not
     clear but every capsule passes its bounds, and the general contact path -- and mixes of them across workgroups.
@@ -116,10 +117,22 @@ def test_broadphase_regimes_match_oracle(z_range):
     rng = np.random.default_rng(17)
     st = _random_state(rng, model, n)
     st["q"][2] = rng.uniform(z_range[0], z_range[1], n)
+    if z_range == (-0.222, -0.216):                  # straight fingers a few mm to 3 cm off the box: capsule bounds fail, nothing touches (the box-only fast-out)
+        st["q"][:2] = rng.uniform(-0.01, 0.01, (2, n)); st["q"][3:6] = 0.0; st["q"][6:] = rng.uniform(0.0, 0.05, (20, n))
+        st["qd"] *= 0.1
+        st["box_pos"][:2] *= 0.3
+        st["q"][2, 64:128] = rng.uniform(-0.43, -0.38, 64)     # ... and one workgroup that does touch
+        # ... and two workgroups in which NO env can touch although the middle finger's capsules fail their bounds: hand centred over
+        # the box, fingertips 2-14 mm above its top face
+        st["q"][:2, 192:] = 0.0; st["q"][2, 192:] = rng.uniform(-0.238, -0.226, 128)
+        st["box_pos"][:2, 192:] = 0.0; st["box_quat"][:, 192:] = np.array([[0.0], [0.0], [0.0], [1.0]])
+        st["box_lin"][:, 192:] = 0.0; st["box_ang"][:, 192:] = 0.0; st["qd"][:, 192:] = 0.0
     st["q"][2, :64] = rng.uniform(-0.1, 0.2, 64)    # first workgroup always far from the box: regimes mix across workgroups
     st["q"] = np.clip(st["q"], model.lo[:, None] + 1e-3, model.hi[:, None] - 1e-3)
     st["targets"] = st["q"] + rng.normal(0, 0.02, (26, n))
     st["qd"] *= 0.2
+    if z_range == (-0.222, -0.216):
+        st["targets"][:, 192:] = st["q"][:, 192:]    # (the hands of the contact-free workgroups hold their pose)
     for k, v in st.items():
         o.set(k, v)
         hb.set(k, v)
@@ -131,6 +144,8 @@ def test_broadphase_regimes_match_oracle(z_range):
         assert nc_o.max() <= 4                       # box/ground contacts only
     if z_range[1] < -0.37:
         assert nc_o.max() >= 5                       # fingers really touch box or ground
+    if z_range == (-0.222, -0.216):
+        assert nc_o[192:].max() <= 4 and nc_o[64:128].max() >= 5
     np.testing.assert_allclose(hb.get("q"), o.get("q"), atol=5e-4)
     np.testing.assert_allclose(hb.get("box_pos"), o.get("box_pos"), atol=5e-4)
     np.testing.assert_allclose(hb.get("box_lin"), o.get("box_lin"), atol=2e-2, rtol=5e-3)
@@ -528,10 +543,15 @@ def test_step_sink_writes_rollout_rows():
         assert torch.equal(rb.slots[0].obs[t], core.obs_buf)
         assert torch.equal(rb.slots[0].rew[t], core.rew_buf)
         assert torch.equal(rb.slots[0].done[t].bool(), core.reset_buf.bool())
+        assert torch.equal(rb.slots[0].stats[t, :20], core.stats[:20])     # dexsim_set_stats_sink: the step's statistics block
     assert rb.full() and int(rb.slots[0].done.sum()) > 0   # timeouts at step 5 really reached the sink
-    obs, rew, done = rb.gather()
+    h = rb.gather_async()
+    obs, rew, done = h()
     assert obs.shape == (8, n, int(sc.num_obs))
+    st = h.stats()                                         # single rank: the whole population is this rank's shard
+    assert float(st["timeout_rate"].max()) == 1.0 and float(st["num_resets"].max()) == n and st["consecutive_successes"].tolist() == [0.0] * 8
     core.set_step_sink(None, None, None)
+    core.set_stats_sink(None)
     before = rb.slots[0].obs[7].clone()
     core.step(a)
     torch.cuda.synchronize()
