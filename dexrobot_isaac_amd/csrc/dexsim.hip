@@ -392,16 +392,24 @@ int dexsim_process_actions(dexsim_t h, const float* actions, int zero_targets, v
 // tail != 0 (gated launch of the step path only): the launch also applies phase 1 of the in-step reset and finalises
 // the step statistics, so that a control step is k_actions, k_physics4, k_post, k_physics4<gated> and nothing else
 static int physics_step(dexsim_t h, int gate_on_reset, int tail, void* stream, const float* actions = nullptr) {
-  if (h->cfg.substeps == 4) {   // the reference's setting: the whole sim.dt in one launch
+  if (h->cfg.substeps % 4 == 0) {
+    // the reference's setting (4): the whole sim.dt in one launch.  Multiples of 4 (round 3: cfg/physics/accurate.yaml = 32): one
+    // launch per four sub-steps -- the action block rides on the first launch, the post-physics block / the reset tail on the
+    // last; launches before the last carry tail bit 2 ("not final": their fourth body does not add to the contact statistics)
     const size_t lds = (size_t)FS_WORDS * 64 * sizeof(float);
     const dim3 grid(h->NS / 64), block(448);
-    if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, tail, h->NS, h->N);
-    else {
-      ApiPtrs api = h->api;
-      if (api.actions_copy == actions) api.actions_copy = nullptr;   // `act` is __restrict__: never alias it with the copy sink
-      k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, api, h->d_params, h->api.counters, actions, tail, h->NS, h->N);
+    const int n4 = h->cfg.substeps / 4;
+    for (int i = 0; i < n4; i++) {
+      const int t = i == n4 - 1 ? tail : 4;
+      const float* act = i == 0 ? actions : nullptr;
+      if (gate_on_reset) k_physics4<true><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, nullptr, t, h->NS, h->N);
+      else {
+        ApiPtrs api = h->api;
+        if (api.actions_copy == act) api.actions_copy = nullptr;   // `act` is __restrict__: never alias it with the copy sink
+        k_physics4<false><<<grid, block, lds, (hipStream_t)stream>>>(h->arena, api, h->d_params, h->api.counters, act, t, h->NS, h->N);
+      }
+      LAUNCH_CHECK();
     }
-    LAUNCH_CHECK();
     return DEXSIM_OK;
   }
   // other sub-step counts: `substeps` fused launches (dynamics + contact solve + integrate); the last one also publishes
@@ -419,7 +427,7 @@ int dexsim_physics_step(dexsim_t h, int gate_on_reset, void* stream) {
 
 int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
   NEED_BOUND(h);
-  const int fused = h->cfg.substeps == 4 && !obs_only;
+  const int fused = h->cfg.substeps % 4 == 0 && !obs_only;
   k_post<<<dim3(h->NS / 64), dim3(512), POST_LDS_BYTES, (hipStream_t)stream>>>(h->arena, h->api, h->d_params, h->api.counters, obs_only, fused, h->NS, h->N);
   LAUNCH_CHECK();
   if (obs_only) return DEXSIM_OK;
@@ -438,7 +446,7 @@ int dexsim_post_physics(dexsim_t h, int obs_only, void* stream) {
 
 int dexsim_step(dexsim_t h, const float* actions, void* stream) {
   NEED_BOUND(h);
-  if (h->cfg.substeps == 4) {
+  if (h->cfg.substeps % 4 == 0) {
     // actions + physics + post-physics (+ phase 0 of the in-step reset) in one launch, then the device-gated extra
     // physics step with phase 1 of the reset and the step statistics: a control step is 2 launches
     if (!actions) return fail(DEXSIM_ERR_ARG, "Actions cannot be None");   // action_processor.py:296-297

@@ -874,11 +874,14 @@ def test_generic_sweep_variants_match_oracle(z):
     assert np.isfinite(hb.get("q")).all() and np.abs(hb.get("q") - o.get("q")).max() < 5e-3
 
 
-@pytest.mark.parametrize("substeps,iters", [(2, 8), (8, 32), (32, 32)], ids=["physics=fast", "8 sub-steps / 32 iterations", "physics=accurate"])
+@pytest.mark.parametrize("substeps,iters", [(2, 8), (6, 16), (8, 32), (32, 32)],
+                         ids=["physics=fast", "6 sub-steps (staged)", "8 sub-steps / 32 iterations", "physics=accurate"])
 def test_other_substep_counts_use_the_staged_path(substeps, iters):
     """cfg/physics/fast.yaml (substeps 2, 8 position iterations), a heavier setting in the direction of
     cfg/physics/accurate.yaml, and accurate.yaml itself at its real 32 sub-steps x 32 iterations (round 3; timed by
-    `bench.py --substeps 32 --iterations 32`): sub-step counts other than 4 run dexsim_step as
+    `bench.py --substeps 32 --iterations 32`).  Multiples of 4 run as one fused launch per four sub-steps (round 3: the action
+    block on the first launch, the post-physics block / reset tail on the last; 32 sub-steps = 8 + 8 launches instead of 32 + 32
+    + the stage kernels); the other counts run dexsim_step as
     the staged launches (k_actions, `substeps` x k_substep, k_post, k_reset, gated physics, k_reset).  Whole control steps
     with in-step resets against the oracle; the integer bookkeeping must agree exactly."""
     from oracle.oracle import Oracle
