@@ -214,13 +214,11 @@ def main():
     gen.manual_seed(1234 + rank)
     n_act = 64                               # distinct pre-generated action batches, cycled
     actions = 2.0 * torch.rand(n_act, N, 18, device=device, generator=gen) - 1.0
-    # Optional pre-roll (--preroll P, stated in the output as config.preroll_steps).  Short timed regions
-    # behind a host synchronisation read low on this part (20 steps: ~57 M env-steps/s against ~64 M over 300; bursts of 16 steps
-    # between synchronisations: 97 us per step against 65, scripts/stagger_probe.py; under rocprofv3 the same launches never slow
-    # down).  With P > 0, P control steps run on a THROW-AWAY env of the same shape immediately before each timed region's
-    # synchronisation (the measured env is not touched: the headline regime is defined by its fresh reset).  Measured in round
-    # 3, twice (once before the warm-up, once right before the synchronisation): 55.5 / 57.4 M with, 57.5 / 57.2 M without -- the
-    # penalty belongs to the first launches AFTER a synchronisation, whatever ran before it.  Off by default.
+    # Optional pre-roll (--preroll P, stated in the output as config.preroll_steps): P control steps on a
+    # THROW-AWAY env of the same shape immediately before each timed region's synchronisation.  Measured in round 3: no effect
+    # (55.5 / 57.4 M with, 57.5 / 57.2 M without).  What a 20-step window behind 5 warm-up steps really paid for was a host read
+    # (`.sum().item()`) between warm-up and window -- ~80 us on the first launches behind it (scripts/warm_profile.py: 61.1 us per
+    # step GPU time without the read, 64.8 with); the read now sits before the warm-up.  Off by default.
     pre = None
     if args.preroll > 0:
         pre = DexSimCore(sc, model.to_struct(), device)
@@ -256,9 +254,12 @@ def main():
             last_handle[0] = pending.pop(0)
             last_handle[0]()
 
+    # (read BEFORE the warm-up: a host read -- torch reduction kernel, device-to-host copy, wait -- between the warm-up and the
+    # timed region costs the first launches behind it ~80 us, 4 us per step of a 20-step window: scripts/warm_profile.py, case B
+    # against case A.  The resets counted therefore include the warm-up's.)
+    resets0 = float(core.field("reset_count").sum().item())
     run(args.warmup)
     keep_busy()
-    resets0 = float(core.field("reset_count").sum().item())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -357,7 +358,7 @@ def main():
                        "parallelism": f"env-shard x{world}", "rollout_gather_horizon": args.horizon if world > 1 else None,
                        "rollout_gather_mode": args.gather if world > 1 else None,
                        "domain_randomisation": bool(args.dr), "joint_limit_rows": bool(args.joint_limit_rows)},
-            "resets_per_step": resets / args.steps,
+            "resets_per_step": resets / (args.steps + args.warmup),      # (over warm-up + timed steps, see resets0)
             # the headline regime's contact set: random actions from the spawn pose never bring a finger to the box, so
             # these are the box's corners on the ground (see contact_rich for the regime the solver exists for)
             "mean_contacts": {"total": kbar, "hand": kbar_hand, "box_ground": kbar - kbar_hand},
