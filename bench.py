@@ -142,6 +142,8 @@ def training_like(args, N, device, gen, steps=200, warm=60, keep_busy=None):
     if keep_busy is not None:
         keep_busy()                                               # (clock pre-roll, see main)
     r0 = float(core.field("reset_count").sum().item())
+    for i in range(5):                                           # (a host read costs the first launches behind it ~80 us: five
+        env.step(acts[i % 16])                                   # un-timed steps between the read and the window, see main)
     kb, kh = [], []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -153,7 +155,7 @@ def training_like(args, N, device, gen, steps=200, warm=60, keep_busy=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     res = {"value": N * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "through": "make_env().step()",
-           "resets_per_step": (float(core.field("reset_count").sum().item()) - r0) / steps,
+           "resets_per_step": (float(core.field("reset_count").sum().item()) - r0) / (steps + 5),
            "mean_contacts": {"total": float(torch.stack(kb).mean().item()), "hand": float(torch.stack(kh).mean().item())},
            "state": "every reset lands hand-on-box (hand base 0.247-0.262 m below spawn: fingertips on the box top, fingers 0-0.3 rad; injected reset samples, "
                     "task.hand_translation_range = 0.40), episode clocks staggered over stage 1, actions 0.2 x U(-1,1)"}
@@ -393,13 +395,14 @@ def main():
             run(50)
             keep_busy()
             r0 = float(core.field("reset_count").sum().item())
+            run(5)                           # (un-timed: the launches right behind a host read run slow, see resets0)
             torch.cuda.synchronize()
             ts = time.perf_counter()
             run(200)
             torch.cuda.synchronize()
             ds = time.perf_counter() - ts
             out["staggered_resets"] = {"value": N * 200 / ds, "unit": "env-steps/s", "ms_per_step": ds / 200 * 1e3,
-                                       "resets_per_step": (float(core.field("reset_count").sum().item()) - r0) / 200}
+                                       "resets_per_step": (float(core.field("reset_count").sum().item()) - r0) / 205}
         if world == 1 and not args.no_contact_rich and args.task == "BlindGrasping":
             # Secondary figure, NOT `value`: every hand lowered onto its box (scripts/contact_regime.py's state) -- the
             # regime a policy that has learnt to grasp lives in.  Timed: back-to-back physics steps (4 sub-steps each,
