@@ -114,3 +114,17 @@ for _ in range(20):
 e1.record(); torch.cuda.synchronize()
 many = e0.elapsed_time(e1) * 1e3 / 20
 print(f"k_physics4 (profile build): {tot} stamp ticks over the four bodies (wave 0, median workgroup); one launch {one:.1f} us, 20 back to back {many:.1f} us each -> {tot / many / 1e3:.2f} ticks per ns")
+
+# the whole control step as the product runs it (actions + 4 bodies + post block in one launch): the last body's stamps for every
+# wave -- who reaches the barrier in front of the post block last -- and the post block's own (relative to its start)
+core.step(a)
+torch.cuda.synchronize()
+crow = core.field("crow").view(torch.int32).cpu().numpy()
+print("full step, last body (median workgroup): phase 5 done | publication (+ the box wave's post pre-tasks) done")
+for wv in range(7):
+    st = np.median(np.array([[crow[64 * 4 + wv * 8 + k, e] for k in range(7)] for e in lanes]), axis=0)
+    print(f"  wave {wv}: {int(st[5])} | {int(st[6])}")
+pn = ["phase A", "phase B", "row flush", "obs_buf flush"]
+for wv in range(7):
+    st = np.array([[crow[wv * 8 + k, e] for k in range(4)] for e in lanes])
+    print(f"  post block wave {wv}: " + "  ".join(f"{nm}={int(v)}" for nm, v in zip(pn, np.median(st, axis=0))))
